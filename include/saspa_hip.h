@@ -1,0 +1,175 @@
+/*
+ * saspa_hip.h -- C ABI of libsaspa_hip.so: the MI355X (gfx950) kernels behind the
+ * SaSPA augmentation-generation hot path.
+ *
+ * The reference (EyalMichaeli/SaSPA-Aug) has NO FFI / native layer: the path sits
+ * behind one Python call, `pipe(**pipe_args)` (run_aug/run_aug.py:278), whose
+ * arithmetic runs inside diffusers/torch CUDA kernels, and behind
+ * `cv2.Canny` (all_utils/utils.py:83).  This header is therefore the boundary a
+ * maintainer binds *instead of* those library calls; each entry point names the
+ * upstream module whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; no allocation, no
+ *     host sync, no hidden stream: work is enqueued on `stream` (a hipStream_t
+ *     passed as void*), so calls are graph-capturable;
+ *   - activations are channels-last: [batch][H*W][C], pixel pitch given in
+ *     elements; dtype selects bf16 (SASPA_BF16) or fp32 (SASPA_F32) storage,
+ *     accumulation is always fp32;
+ *   - weights are [N][K] with K contiguous (conv: K = (ky*kw+kx)*Cin + c);
+ *   - bias / norm parameters / per-batch vectors are always fp32;
+ *   - return value 0 on success, negative SASPA_E* on a rejected argument
+ *     (checked on the host BEFORE any launch), positive = hipError_t of the launch.
+ */
+#ifndef SASPA_HIP_H
+#define SASPA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SASPA_BF16 0
+#define SASPA_F32 1
+
+#define SASPA_EINVAL (-1) /* null pointer / non-positive size */
+#define SASPA_EALIGN (-2) /* channel count, pitch or pointer not 16-byte compatible */
+#define SASPA_ERANGE (-3) /* shape outside what the kernel supports */
+
+#define SASPA_ACT_NONE 0
+#define SASPA_ACT_SILU 1
+
+/* ---- implicit-GEMM convolution / linear ----------------------------------
+ * out[m][n] = act( alpha * (sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n]) ) + residual[m][n]
+ * where m = (b, oy, ox) and A is the im2col view of up to two channel-concatenated
+ * NHWC sources (skip-concat of the UNet up blocks), optionally nearest-x2 upsampled.
+ * Replaces: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv, Upsample2D
+ * (interpolate+conv), Transformer2DModel.proj_in/proj_out, Attention.to_q/k/v/to_out,
+ * GEGLU.proj, FeedForward.net.2, time_emb_proj, ControlNet zero convs and
+ * cond-embedding, VAE decoder convs, CLIP linears (a7.1, a7.5, a7.6, a7.8).
+ * A linear layer is the kh=kw=1 case with batch=1, hin=hout=M, win=wout=1.
+ * Batched use (nb1*nb2 independent problems, element strides per operand) serves
+ * the unfused attention path (scores = Q K^T, out = P V) and the V^T projection. */
+typedef struct SaspaGemmParams {
+  int dtype;                 /* SASPA_BF16 | SASPA_F32 (A, W, residual, out) */
+  const void* a0;            /* source 0, NHWC */
+  const void* a1;            /* source 1 (channels appended after source 0) or NULL */
+  int c0, c1;                /* channels taken from each source (multiples of 8) */
+  int lda0, lda1;            /* pixel pitch of each source, elements */
+  int batch, hin, win;       /* stored input extent */
+  int hout, wout;            /* output extent */
+  int kh, kw, stride, pad;   /* kernel window */
+  int upsample;              /* 1: conv sees the input nearest-upsampled x2 */
+  const void* w;             /* [N][K] */
+  int ldw;                   /* row pitch of w, elements */
+  int M, N, K;               /* M = batch*hout*wout, K = kh*kw*(c0+c1) */
+  const float* bias;         /* [N] or NULL */
+  const float* rowvec;       /* [batch or 1][N] or NULL (time-embedding projection) */
+  int ldrv;                  /* batch pitch of rowvec (0: same vector for every batch) */
+  const void* residual;      /* [M][N] or NULL */
+  int ldr;
+  float alpha;
+  int act;                   /* SASPA_ACT_* */
+  void* out;                 /* [M][N] */
+  int ldo;
+  /* batching: problem index z = i1*nb2 + i2 */
+  int nb1, nb2;
+  long long sa1, sa2;        /* element strides of a0 */
+  long long sw1, sw2;        /* element strides of w */
+  long long so1, so2;        /* element strides of out (and residual) */
+} SaspaGemmParams;
+int saspa_gemm(const SaspaGemmParams* p, void* stream);
+
+/* ---- fused flash attention (bf16) -----------------------------------------
+ * O[b][i][h*D+d] = sum_j softmax_j(scale * Q[b][i][h,:] . K[b][j][h,:]) * V[b][j][h,d]
+ * V is consumed TRANSPOSED: vt[b][(h*D+d)][j] (produced by saspa_gemm with the
+ * operands swapped), keys j >= nk are masked; causal=1 additionally masks j > i
+ * (CLIP text tower).  Replaces AttnProcessor2_0 / F.scaled_dot_product_attention in
+ * BasicTransformerBlock.attn1/attn2 and CLIPAttention (a7.1, a7.5, a7.6). */
+typedef struct SaspaAttnParams {
+  const void* q; int ldq; long long sqb;   /* [B][nq][heads*D], row pitch, batch stride (elements) */
+  const void* k; int ldk; long long skb;   /* [B][nk][heads*D] */
+  const void* vt; int ldvt; long long svb; /* [B][heads*D][ldvt >= nk] */
+  void* o; int ldo; long long sob;
+  int batch, heads, D;                     /* D multiple of 8, <= 160 */
+  int nq, nk;
+  float scale;
+  int causal;
+} SaspaAttnParams;
+int saspa_flash_attn_bf16(const SaspaAttnParams* p, void* stream);
+
+/* row softmax in place over a [rows][ld] matrix (unfused attention path: fp32
+ * parity mode and the 512-wide single-head VAE attention): x = softmax(scale*x) over
+ * the first n columns; causal: row r of each `rows_per_mat` block only sees cols <= r. */
+int saspa_softmax_rows(int dtype, void* x, long long rows, int n, int ld, float scale,
+                       int causal, int rows_per_mat, void* stream);
+
+/* ---- GroupNorm (+SiLU): NHWC, two launches -------------------------------
+ * stats: per (batch, channel) sums -> per (batch, group) mean/rstd folded with
+ * gamma/beta into scale/shift[b][c];  apply: y = act(x*scale + shift).
+ * Replaces ResnetBlock2D.norm1/norm2 (+SiLU), Transformer2DModel.norm, conv_norm_out,
+ * VAE GroupNorms (a7.5, a7.6, a7.8).
+ * x may be the channel concat of two sources (x1 != NULL). */
+typedef struct SaspaGroupNormParams {
+  int dtype;
+  const void* x0; const void* x1;
+  int c0, c1, ldx0, ldx1;
+  int batch, hw, groups;
+  float eps;
+  const float* gamma; const float* beta;  /* [C] */
+  float* partial;        /* workspace: batch * nsplit * C * 2 floats */
+  int nsplit;
+  float* scale_shift;    /* out: [batch][2][C] */
+  int act;
+  void* y; int ldy;      /* apply output [batch*hw][C] */
+} SaspaGroupNormParams;
+int saspa_groupnorm_stats(const SaspaGroupNormParams* p, void* stream);
+int saspa_groupnorm_apply(const SaspaGroupNormParams* p, void* stream);
+
+/* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, CLIP LNs). */
+int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int C,
+                    const float* gamma, const float* beta, float eps, void* stream);
+
+/* ---- elementwise ----------------------------------------------------------*/
+/* GEGLU: y[m][f] = x[m][f] * gelu_erf(x[m][F+f])   (diffusers GEGLU) */
+int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int F, void* stream);
+/* act: 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) (CLIP MLP); in/out [rows][C] */
+int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
+                     void* stream);
+/* CLIP embeddings: out[i][:] = tok[ids[i]][:] + pos[i % npos][:] */
+int saspa_embed_tokens(int dtype, const int* ids, int n, int npos, const void* tok, const void* pos, int C,
+                       void* out, void* stream);
+/* classifier-free guidance + DDIM step (eta=0), fused; writes x_prev into both
+ * CFG halves of the model-input buffer.  eps: [2*nimg][hw][ldc] (uncond first),
+ * x: [2*nimg][hw][ldc]; channels c < C are live.
+ *   e = eu + g*(ec-eu); x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); x' = sqrt(a_p) x0 + sqrt(1-a_p) e
+ * Replaces the CFG lines + DDIMScheduler.step (a7.4, a7.7). */
+int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc,
+                        float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                        float sqrt_1m_a_prev, void* stream);
+/* y = x * s  (latents / scaling_factor before the VAE) */
+int saspa_scale(int dtype, const void* x, void* y, long long n, float s, void* stream);
+/* u8 RGB [n][H*W][3] -> [n][H*W][8] activations in [0,1], pad channels zero
+ * (VaeImageProcessor.preprocess with do_normalize=False; SURVEY 8a: a7.2) */
+int saspa_u8_to_act(int dtype, const uint8_t* src, void* dst, long long npix, void* stream);
+/* VAE output [npix][ldx] (3 live channels) -> u8 RGB: round(255*clamp(x/2+0.5,0,1))
+ * (VaeImageProcessor.postprocess; SURVEY 8a: a7.10) */
+int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, long long npix, void* stream);
+
+/* ---- Canny edge extractor (integer exact vs cv2.Canny, aperture 3, L1) ------
+ * src: u8 [n][H][W][3]; dst: u8 [n][H][W][3] in {0,255} (HWC3 replicated);
+ * work: 8*n*H*W bytes of scratch.  The hysteresis bitmaps of one image live in one
+ * CU's LDS: 2*H*ceil(W/32)*4 bytes must fit 160 KiB (e.g. 512x1280), else SASPA_ERANGE.
+ * Replaces all_utils/utils.py:81-99 CannyDetector/preprocess_canny (a6). */
+int saspa_canny(const uint8_t* src, uint8_t* dst, uint8_t* work, int n, int H, int W, int low, int high,
+                void* stream);
+
+/* library self-description */
+int saspa_abi_version(void);
+const char* saspa_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SASPA_HIP_H */

@@ -1,0 +1,85 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU fp32 restatement of
+``StableDiffusionControlNetPipeline.__call__`` exactly as the reference invokes
+it (run_aug/run_aug.py:235-241, :268-269, :278): CFG with a negative prompt,
+Canny control image, DDIM (scheduler built at run_aug/run_aug.py:221 from the
+SD-1.5 config), eta=0, conditioning scale 0.75, output_type "pil".
+
+PARITY UNPINNED (see oracle/__init__.py).
+"""
+import numpy as np
+import torch
+
+from . import sd_models as M
+
+
+class DDIM:
+    """DDIMScheduler.from_config(SD-1.5 scheduler config): scaled_linear betas
+    0.00085..0.012 over 1000 steps, steps_offset=1, set_alpha_to_one=False,
+    clip_sample=False, epsilon prediction, "leading" spacing."""
+
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_train = num_train
+        self.steps_offset = steps_offset
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        self.n = n
+        ratio = self.num_train // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        self.timesteps = ts
+        return ts
+
+    def coefficients(self, t):
+        prev_t = int(t) - self.num_train // self.n
+        a_t = self.alphas_cumprod[int(t)]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return a_t, a_prev
+
+    def step(self, eps, t, x):
+        a_t, a_prev = self.coefficients(t)
+        beta_t = 1 - a_t
+        x0 = (x - beta_t ** 0.5 * eps) / a_t ** 0.5
+        direction = (1 - a_prev) ** 0.5 * eps          # eta = 0 -> std_dev_t = 0
+        return a_prev ** 0.5 * x0 + direction
+
+
+def prepare_control(control_u8):
+    """VaeImageProcessor(do_normalize=False).preprocess: u8 HWC RGB -> [1,3,H,W] in [0,1]."""
+    x = torch.from_numpy(np.ascontiguousarray(control_u8)).float() / 255.0
+    return x.permute(2, 0, 1)[None]
+
+
+def postprocess(img):
+    """VaeImageProcessor.postprocess('pil') up to the uint8 array."""
+    x = (img / 2 + 0.5).clamp(0, 1)
+    x = x.permute(0, 2, 3, 1).float().numpy()
+    return (x * 255).round().astype("uint8")
+
+
+@torch.no_grad()
+def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents, steps,
+                           guidance_scale=7.5, conditioning_scale=0.75, return_latents=False):
+    """weights: dict(unet=, controlnet=, vae=, text=) of diffusers-named state dicts.
+    ids_*: int64 [1,77].  control_u8: u8 [H,W,3].  latents: fp32 [1,4,H/8,W/8] noise.
+    Returns u8 [1,H,W,3] (and the final latents / decoded float image if asked)."""
+    ctx = M.clip_text_forward(weights["text"], cfgs["text"], torch.cat([ids_neg, ids_pos], 0))
+    cond = prepare_control(control_u8)
+    cond2 = torch.cat([cond, cond], 0)
+    sch = DDIM()
+    x = latents.clone().float() * sch.init_noise_sigma
+    for t in sch.set_timesteps(steps):
+        x2 = torch.cat([x, x], 0)
+        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x2, int(t), ctx, cond2,
+                                         conditioning_scale)
+        eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
+        eps_u, eps_c = eps2.chunk(2)
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        x = sch.step(eps, t, x)
+    img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
+    out = postprocess(img)
+    if return_latents:
+        return out, x, img
+    return out

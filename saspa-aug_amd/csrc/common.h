@@ -1,0 +1,104 @@
+// Shared device helpers for the gfx950 kernels of libsaspa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "saspa_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define SASPA_CHECK_LAUNCH()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __builtin_bit_cast(float, hi16 << 16); }
+
+// unpack 8 bf16 (one 16-byte chunk) to fp32
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  f[0] = __builtin_bit_cast(float, u.x << 16);
+  f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, u.y << 16);
+  f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+  f[4] = __builtin_bit_cast(float, u.z << 16);
+  f[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+  f[6] = __builtin_bit_cast(float, u.w << 16);
+  f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = pack2(f[0], f[1]);
+  u.y = pack2(f[2], f[3]);
+  u.z = pack2(f[4], f[5]);
+  u.w = pack2(f[6], f[7]);
+  return u;
+}
+
+// ---- dtype-generic "vector of V contiguous elements" load/store as fp32 ----
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  static constexpr int EPC = 8;  // elements per 16-byte chunk
+  __device__ static __forceinline__ void load_chunk(const bf16_t* p, float* f) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    unpack8(u, f);
+  }
+  __device__ static __forceinline__ void store_chunk(bf16_t* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = pack8(f);
+  }
+  __device__ static __forceinline__ void load4(const bf16_t* p, float* f) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    f[0] = __builtin_bit_cast(float, u.x << 16);
+    f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, u.y << 16);
+    f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store4(bf16_t* p, const float* f) {
+    uint2 u;
+    u.x = pack2(f[0], f[1]);
+    u.y = pack2(f[2], f[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+  __device__ static __forceinline__ float load1(const bf16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void store1(bf16_t* p, float f) { *p = (bf16_t)f; }
+};
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;
+  __device__ static __forceinline__ void load_chunk(const float* p, float* f) {
+    float4 u = *reinterpret_cast<const float4*>(p);
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
+  }
+  __device__ static __forceinline__ void store_chunk(float* p, const float* f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+  __device__ static __forceinline__ void load4(const float* p, float* f) { load_chunk(p, f); }
+  __device__ static __forceinline__ void store4(float* p, const float* f) { store_chunk(p, f); }
+  __device__ static __forceinline__ float load1(const float* p) { return *p; }
+  __device__ static __forceinline__ void store1(float* p, float f) { *p = f; }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,266 @@
+// Fused flash attention (bf16, fp32 accumulate) for gfx950 and the row-softmax used
+// by the unfused (fp32 parity / VAE 512-wide head) path.  See include/saspa_hip.h.
+//
+// Formulation (per wave: 32 queries, per workgroup: 4 waves = 128 queries, KV tile = 64 keys):
+//   S^T = K Q^T     v_mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers).
+//                   The accumulator then has the QUERY on the lane (column) and 16 of the
+//                   32 keys in registers, so the softmax max / sum are in-register plus one
+//                   exchange with lane^32, and the O rescale is a per-lane scalar.
+//   O^T += V^T P^T  P^T (bf16-packed accumulator registers 8s..8s+7) is directly the B
+//                   operand of the next MFMA; its k order inside a 16-key step is
+//                   key = 8*(j>>2) + 4*(lane>>5) + (j&3), so the A operand (V^T rows, keys
+//                   contiguous) is read as two 8-byte pieces at key offsets 4h and 8+4h.
+//   V^T comes from the value projection computed with swapped GEMM operands
+//   (vt[b] = Wv x_b^T), so no transpose pass exists anywhere.
+// LDS images: K tile rows padded to an odd number of 16-byte slots (conflict-free
+// ds_read_b128 across 32 distinct rows); V^T rows = 64 keys + 8 bytes pad (conflict-free
+// ds_read_b64: row stride 136 B = 8*17).
+#include "common.h"
+
+namespace {
+
+template <int KS, int NB>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
+  constexpr int KSLOTS = (2 * KS) | 1;       // 16-byte slots per K row (odd)
+  constexpr int KCH = 2 * KS;                // chunks per K row that are written
+  constexpr int DV = NB * 32;
+  constexpr int VROW = 136;                  // bytes
+  constexpr int K_BYTES = 64 * KSLOTS * 16;
+  constexpr int V_BYTES = DV * VROW;
+  constexpr int NCH_K = (64 * KCH + 255) / 256;
+  constexpr int NCH_V = (DV * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
+  unsigned char* ksm = smem;
+  unsigned char* vsm = smem + K_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int D = p.D, D8 = D >> 3;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + r;  // this lane's query
+
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // ---- Q fragments (B operand), resident for the whole kernel ----
+  u32x4 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int d = 16 * s + 8 * h;
+    qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
+  }
+
+  f32x16 acc_o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale * 1.4426950408889634f;
+
+  const int ntiles = (p.nk + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * 64;
+    // ---- stage K tile [64][D] and V^T tile [D][64] ----
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i) {
+      const int q = tid + 256 * i;
+      if (q < 64 * KCH) {
+        const int key = q / KCH, ch = q - key * KCH;
+        u32x4 v = zero4;
+        if (ch < D8 && key0 + key < p.nk) v = *reinterpret_cast<const u32x4*>(Kp + (long long)(key0 + key) * p.ldk + ch * 8);
+        *reinterpret_cast<u32x4*>(ksm + (key * KSLOTS + ch) * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      const int q = tid + 256 * i;
+      if (q < DV * 8) {
+        const int d = q >> 3, kc = q & 7;
+        const int kk = key0 + kc * 8;
+        u32x4 v = zero4;
+        if (d < D && kk < p.nk) {
+          v = *reinterpret_cast<const u32x4*>(VT + (long long)d * p.ldvt + kk);
+          const int nvalid = p.nk - kk;  // >= 1
+          if (nvalid < 8) {
+            // zero the keys >= nk (pad columns of vt are not initialised by the producer)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (2 * e >= nvalid) v[e] = 0;
+              else if (2 * e + 1 >= nvalid) v[e] &= 0x0000ffffu;
+            }
+          }
+        }
+        u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
+        dst[0] = u32x2{v.x, v.y};
+        dst[1] = u32x2{v.z, v.w};
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for two 32-key blocks ----
+    f32x16 acc_s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_s[kb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
+        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                            __builtin_bit_cast(bf16x8, qf[s]), acc_s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask + online softmax (query on the lane) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        float sc = acc_s[kb][i] * c;
+        if (key >= p.nk || (p.causal && key > qi)) sc = -INFINITY;
+        acc_s[kb][i] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(acc_s[kb][i] - m_new);
+        acc_s[kb][i] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kb = ks >> 1, half = ks & 1;
+      u32x4 pf;
+      pf.x = pack2(acc_s[kb][8 * half + 0], acc_s[kb][8 * half + 1]);
+      pf.y = pack2(acc_s[kb][8 * half + 2], acc_s[kb][8 * half + 3]);
+      pf.z = pack2(acc_s[kb][8 * half + 4], acc_s[kb][8 * half + 5]);
+      pf.w = pack2(acc_s[kb][8 * half + 6], acc_s[kb][8 * half + 7]);
+      const int koff = (kb * 32 + 16 * half + 4 * h) * 2;  // bytes
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + koff;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+        const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
+        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                            __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[qi][d], d = 32*nb + 8*g + 4*h + (0..3) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qi < p.nq) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * nb + 8 * g + 4 * h;
+        if (d < D) {
+          float v[4] = {acc_o[nb][4 * g + 0] * inv, acc_o[nb][4 * g + 1] * inv, acc_o[nb][4 * g + 2] * inv,
+                        acc_o[nb][4 * g + 3] * inv};
+          Elem<bf16_t>::store4(O + (long long)qi * p.ldo + d, v);
+        }
+      }
+  }
+}
+
+template <int KS, int NB>
+int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
+  dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
+  hipLaunchKernelGGL((flash_attn_kernel<KS, NB>), grid, dim3(256), 0, s, p);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- row softmax (unfused path) ----
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, long long rows, int n, int ld, float scale, int causal,
+                                                          int rows_per_mat) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T* xr = x + row * ld;
+  int nvis = n;
+  if (causal) {
+    const int rloc = (int)(row % rows_per_mat);
+    nvis = min(n, rloc + 1);
+  }
+  float mx = -INFINITY;
+  for (int j = lane; j < nvis; j += 64) mx = fmaxf(mx, Elem<T>::load1(xr + j) * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nvis; j += 64) sum += expf(Elem<T>::load1(xr + j) * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < ld; j += 64) {
+    float v = 0.f;
+    if (j < nvis) v = expf(Elem<T>::load1(xr + j) * scale - mx) * inv;
+    Elem<T>::store1(xr + j, v);
+  }
+}
+
+}  // namespace
+
+extern "C" int saspa_flash_attn_bf16(const SaspaAttnParams* pp, void* stream) {
+  if (!pp) return SASPA_EINVAL;
+  const SaspaAttnParams& p = *pp;
+  if (!p.q || !p.k || !p.vt || !p.o) return SASPA_EINVAL;
+  if (p.batch <= 0 || p.heads <= 0 || p.nq <= 0 || p.nk <= 0 || p.D <= 0) return SASPA_EINVAL;
+  if (p.D % 8 || p.D > 160) return SASPA_ERANGE;
+  if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4 || p.sqb % 8 || p.skb % 8 || p.svb % 8 || p.sob % 4) return SASPA_EALIGN;
+  if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.vt) || !aligned16(p.o)) return SASPA_EALIGN;
+  if (p.ldvt < ((p.nk + 7) / 8) * 8) return SASPA_ERANGE;
+  if (p.ldq < p.heads * p.D || p.ldk < p.heads * p.D || p.ldo < p.heads * p.D) return SASPA_ERANGE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int D = p.D;
+  if (D <= 16) return launch_attn<1, 1>(p, s);
+  if (D <= 32) return launch_attn<2, 1>(p, s);
+  if (D <= 48) return launch_attn<3, 2>(p, s);
+  if (D <= 64) return launch_attn<4, 2>(p, s);
+  if (D <= 80) return launch_attn<5, 3>(p, s);
+  if (D <= 96) return launch_attn<6, 3>(p, s);
+  if (D <= 128) return launch_attn<8, 4>(p, s);
+  return launch_attn<10, 5>(p, s);
+}
+
+extern "C" int saspa_softmax_rows(int dtype, void* x, long long rows, int n, int ld, float scale, int causal,
+                                  int rows_per_mat, void* stream) {
+  if (!x || rows <= 0 || n <= 0 || ld < n) return SASPA_EINVAL;
+  if (causal && rows_per_mat <= 0) return SASPA_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)x, rows, n, ld, scale, causal, rows_per_mat);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)x, rows, n, ld, scale, causal, rows_per_mat);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}

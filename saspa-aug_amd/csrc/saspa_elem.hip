@@ -1,0 +1,252 @@
+// Elementwise / data-movement kernels of the sampling loop (all HBM-bound, 16-byte vectors
+// per lane, grid-stride with a capped grid).  See include/saspa_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 8192;
+inline unsigned grid_for(long long items) {
+  long long b = (items + 255) / 256;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float* v) {
+  if constexpr (sizeof(T) == 2) {
+    Elem<T>::load_chunk(p, v);
+  } else {
+    Elem<T>::load_chunk(p, v);
+    Elem<T>::load_chunk(p + 4, v + 4);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    Elem<T>::store_chunk(p, v);
+  } else {
+    Elem<T>::store_chunk(p, v);
+    Elem<T>::store_chunk(p + 4, v + 4);
+  }
+}
+
+// GEGLU: y[m][f] = x[m][f] * gelu_erf(x[m][F + f])
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* x, int ldx, T* y, int ldy, long long rows, int F) {
+  const int F8 = F >> 3;
+  const long long total = rows * F8;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const long long row = it / F8;
+    const int f = (int)(it - row * F8) * 8;
+    float a[8], g[8];
+    load8(x + row * ldx + f, a);
+    load8(x + row * ldx + F + f, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = a[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752440f)));
+    store8(y + row * ldy + f, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void activation_kernel(int act, const T* x, int ldx, T* y, int ldy, long long rows, int C) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const long long row = it / C8;
+    const int c = (int)(it - row * C8) * 8;
+    float a[8];
+    load8(x + row * ldx + c, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (act == 1) a[j] = silu_f(a[j]);
+      else a[j] = a[j] / (1.0f + expf(-1.702f * a[j]));
+    }
+    store8(y + row * ldy + c, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* ids, int n, int npos, const T* tok, const T* pos, int C,
+                                                           T* out) {
+  const int C8 = C >> 3;
+  const long long total = (long long)n * C8;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int i = (int)(it / C8);
+    const int c = (int)(it - (long long)i * C8) * 8;
+    float a[8], b[8];
+    load8(tok + (long long)ids[i] * C + c, a);
+    load8(pos + (long long)(i % npos) * C + c, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    store8(out + (long long)i * C + c, a);
+  }
+}
+
+// CFG + DDIM (eta = 0).  One item = one pixel (ldc == 8 channels, C live).
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* eps, T* x, int nimg, long long hw, int C, float g, float sa_t,
+                                                       float s1m_t, float sa_p, float s1m_p) {
+  const long long total = (long long)nimg * hw;
+  const long long half = total * 8;  // elements in one CFG half
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    float eu[8], ec[8], xv[8], o[8];
+    load8(eps + it * 8, eu);
+    load8(eps + half + it * 8, ec);
+    load8(x + it * 8, xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = eu[j] + g * (ec[j] - eu[j]);
+      const float x0 = (xv[j] - s1m_t * e) / sa_t;
+      o[j] = (j < C) ? (sa_p * x0 + s1m_p * e) : 0.f;
+    }
+    store8(x + it * 8, o);
+    store8(x + half + it * 8, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const T* x, T* y, long long n8, float s) {
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < n8; it += (long long)gridDim.x * 256) {
+    float a[8];
+    load8(x + it * 8, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= s;
+    store8(y + it * 8, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void u8_to_act_kernel(const uint8_t* src, T* dst, long long npix) {
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < npix; it += (long long)gridDim.x * 256) {
+    const uint8_t* s = src + it * 3;
+    float a[8] = {s[0] / 255.0f, s[1] / 255.0f, s[2] / 255.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    store8(dst + it * 8, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_to_u8_kernel(const T* x, int ldx, uint8_t* dst, long long npix) {
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < npix; it += (long long)gridDim.x * 256) {
+    float a[4];
+    Elem<T>::load4(x + it * ldx, a);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float v = a[j] / 2.0f + 0.5f;
+      v = fminf(fmaxf(v, 0.0f), 1.0f);
+      dst[it * 3 + j] = (uint8_t)rintf(v * 255.0f);
+    }
+  }
+}
+
+}  // namespace
+
+
+extern "C" int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int F, void* stream) {
+  if (!x || !y || rows <= 0 || F <= 0) return SASPA_EINVAL;
+  if (F % 8 || ldx % 8 || ldy % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
+  if (ldx < 2 * F || ldy < F) return SASPA_ERANGE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(geglu_kernel<bf16_t>, dim3(grid_for(rows * (F / 8))), dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, F);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(geglu_kernel<float>, dim3(grid_for(rows * (F / 8))), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, rows, F);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
+                                void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0 || (act != 1 && act != 2)) return SASPA_EINVAL;
+  if (C % 8 || ldx % 8 || ldy % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(activation_kernel<bf16_t>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, act, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, C);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(activation_kernel<float>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, act, (const float*)x, ldx, (float*)y, ldy, rows, C);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_embed_tokens(int dtype, const int* ids, int n, int npos, const void* tok, const void* pos, int C,
+                                  void* out, void* stream) {
+  if (!ids || !tok || !pos || !out || n <= 0 || npos <= 0 || C <= 0) return SASPA_EINVAL;
+  if (C % 8 || !aligned16(tok) || !aligned16(pos) || !aligned16(out)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3(grid_for((long long)n * (C / 8))), dim3(256), 0, s, ids, n, npos, (const bf16_t*)tok, (const bf16_t*)pos, C, (bf16_t*)out);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3(grid_for((long long)n * (C / 8))), dim3(256), 0, s, ids, n, npos, (const float*)tok, (const float*)pos, C, (float*)out);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc,
+                                   float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
+                                   float sqrt_1m_a_prev, void* stream) {
+  if (!eps || !x || nimg <= 0 || hw <= 0 || C <= 0) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x)) return SASPA_EALIGN;
+  if (!(sqrt_a_t > 0.f)) return SASPA_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_scale(int dtype, const void* x, void* y, long long n, float sc, void* stream) {
+  if (!x || !y || n <= 0) return SASPA_EINVAL;
+  if (n % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n / 8, sc);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(scale_kernel<float>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const float*)x, (float*)y, n / 8, sc);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_u8_to_act(int dtype, const uint8_t* src, void* dst, long long npix, void* stream) {
+  if (!src || !dst || npix <= 0) return SASPA_EINVAL;
+  if (!aligned16(dst)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(u8_to_act_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, src, (bf16_t*)dst, npix);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(u8_to_act_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, s, src, (float*)dst, npix);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, long long npix, void* stream) {
+  if (!x || !dst || npix <= 0) return SASPA_EINVAL;
+  if (ldx % 4 || ldx < 4 || !aligned16(x)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(act_to_u8_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, (const bf16_t*)x, ldx, dst, npix);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(act_to_u8_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, s, (const float*)x, ldx, dst, npix);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_abi_version(void) { return 1; }
+extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

@@ -1,0 +1,285 @@
+// Implicit-GEMM convolution / linear on gfx950 MFMA (bf16: v_mfma_f32_16x16x32_bf16,
+// fp32 parity mode: v_mfma_f32_16x16x4_f32).  See include/saspa_hip.h (SaspaGemmParams).
+//
+// Structure (one workgroup = 4 waves in a 2x2 grid, each wave WM x WN tiles of 16x16):
+//   * A operand = im2col view of up to two channel-concatenated NHWC tensors (optionally
+//     nearest-x2 upsampled), B operand = weights [N][K]; both K-contiguous, so one
+//     16-byte chunk per lane is exactly one MFMA fragment (8 bf16 / 4 fp32 along K).
+//   * K-tile = 128 bytes per row for both dtypes (64 bf16 / 32 fp32): the LDS image, its
+//     XOR swizzle (chunk ^ (row & 7): conflict-free for ds_read_b128 row reads) and the
+//     staging code are shared between the two precisions.
+//   * register-staged double buffering (global -> VGPR issued before the MFMA block of the
+//     current tile, VGPR -> LDS after it, one barrier per K-tile).
+//   * the MFMA computes D^T (weights as the A operand) so every lane ends up with 4
+//     consecutive output channels of one pixel: 8/16-byte epilogue accesses for bias,
+//     time-embedding row vector, residual and the store.
+#include "common.h"
+
+namespace {
+
+struct RowState {
+  int iy0, ix0;   // top-left input coordinate of the window (virtual, i.e. after upsample)
+  int pix0;       // b * hin * win
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4& wf, const u32x4& xf, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
+                                                  acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // one 16-byte chunk = 4 consecutive k per lane; lane group g = lane>>4 owns chunk
+  // (4*kk + g), so MFMA step j pairs element j of every group: the k order is a fixed
+  // permutation shared by both operands (exact fp32 fma chain per output).
+  __device__ static __forceinline__ void run(const u32x4& wf, const u32x4& xf, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.x), __builtin_bit_cast(float, xf.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.y), __builtin_bit_cast(float, xf.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.z), __builtin_bit_cast(float, xf.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, xf.w), acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
+  constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
+  __shared__ u32x4 lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bn = blockIdx.x, bm = blockIdx.y;
+  const int z = blockIdx.z;
+  const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
+
+  const T* a0 = reinterpret_cast<const T*>(p.a0) + (i1 * p.sa1 + i2 * p.sa2);
+  const T* a1 = reinterpret_cast<const T*>(p.a1);
+  const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
+  const long long ooff = i1 * p.so1 + i2 * p.so2;
+
+  // ---- loader state ----
+  const int kc = tid & 7;
+  const int r0 = tid >> 3;  // rows r0 + 32*i
+  const int hw = p.hout * p.wout;
+  RowState rs[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = bm * BM + r0 + 32 * i;
+    if (m < p.M) {
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / p.wout;
+      const int ox = rem - oy * p.wout;
+      rs[i].iy0 = oy * p.stride - p.pad;
+      rs[i].ix0 = ox * p.stride - p.pad;
+      rs[i].pix0 = b * p.hin * p.win;
+    } else {
+      rs[i].iy0 = -(1 << 28);
+      rs[i].ix0 = -(1 << 28);
+      rs[i].pix0 = 0;
+    }
+  }
+  const T* wrow[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int n = bn * BN + r0 + 32 * i;
+    wrow[i] = (n < p.N) ? (w + (long long)n * p.ldw) : nullptr;
+  }
+  const int ctot = p.c0 + p.c1;
+  const int hv = p.upsample ? 2 * p.hin : p.hin;
+  const int wv = p.upsample ? 2 * p.win : p.win;
+  int k = kc * EPC;
+  int tap = k / ctot;
+  int c = k - tap * ctot;
+  int dy = tap / p.kw;
+  int dx = tap - dy * p.kw;
+
+  u32x4 ra[A_CH], rb[B_CH];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&]() __attribute__((always_inline)) {
+    const bool kvalid = k < p.K;
+    const T* src;
+    int ld, cc;
+    if (c < p.c0) { src = a0; ld = p.lda0; cc = c; } else { src = a1; ld = p.lda1; cc = c - p.c0; }
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      int iy = rs[i].iy0 + dy, ix = rs[i].ix0 + dx;
+      const bool inb = kvalid && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
+      if (p.upsample) { iy >>= 1; ix >>= 1; }
+      const long long off = (long long)(rs[i].pix0 + iy * p.win + ix) * ld + cc;
+      ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      rb[i] = (kvalid && wrow[i] != nullptr) ? *reinterpret_cast<const u32x4*>(wrow[i] + k) : zero4;
+    }
+    k += BK;
+    c += BK;
+    while (c >= ctot) {
+      c -= ctot;
+      if (++dx == p.kw) { dx = 0; ++dy; }
+    }
+  };
+  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+    u32x4* la = lds + stage * STAGE;
+    u32x4* lb = la + BM * 8;
+    const int sw = kc ^ (r0 & 7);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) la[(r0 + 32 * i) * 8 + sw] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) lb[(r0 + 32 * i) * 8 + sw] = rb[i];
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fg = lane >> 4;
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const u32x4* la = lds + stage * STAGE;
+    const u32x4* lb = la + BM * 8;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = kk * 4 + fg;
+      u32x4 xa[WM], wb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * (16 * WM) + i * 16 + frow;
+        xa[i] = la[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int row = wn * (16 * WN) + j * 16 + frow;
+        wb[j] = lb[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) Mma<T>::run(wb[j], xa[i], acc[i][j]);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1) < nk;
+    if (more) load_tile();
+    compute(kt & 1);
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds out[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) ----
+  T* out = reinterpret_cast<T*>(p.out) + ooff;
+  const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + ooff : nullptr;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int m = bm * BM + wm * (16 * WM) + i * 16 + frow;
+    if (m >= p.M) continue;
+    const float* rv = nullptr;
+    if (p.rowvec) rv = p.rowvec + (long long)(m / hw) * p.ldrv;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = bn * BN + wn * (16 * WN) + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (n + 3 < p.N) {
+        if (p.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (rv) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= p.alpha;
+          if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
+        }
+        if (res) {
+          float rr[4];
+          Elem<T>::load4(res + (long long)m * p.ldr + n, rr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        Elem<T>::store4(out + (long long)m * p.ldo + n, v);
+      } else {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          float x = v[r];
+          if (p.bias) x += p.bias[n + r];
+          if (rv) x += rv[n + r];
+          x *= p.alpha;
+          if (p.act == SASPA_ACT_SILU) x = silu_f(x);
+          if (res) x += Elem<T>::load1(res + (long long)m * p.ldr + n + r);
+          Elem<T>::store1(out + (long long)m * p.ldo + n + r, x);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int WM, int WN>
+int launch(const SaspaGemmParams& p, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb1 * p.nb2);
+  hipLaunchKernelGGL((gemm_kernel<T, WM, WN>), grid, dim3(256), 0, s, p);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+int dispatch(const SaspaGemmParams& p, hipStream_t s) {
+  const long long nb = (long long)p.nb1 * p.nb2;
+  if (p.N <= 32) return launch<T, 4, 1>(p, s);
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
+  if (tiles128 >= 192 && p.N > 64) return launch<T, 4, 4>(p, s);
+  return launch<T, 2, 2>(p, s);
+}
+
+}  // namespace
+
+extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
+  if (!pp) return SASPA_EINVAL;
+  SaspaGemmParams p = *pp;
+  if (p.nb1 <= 0) p.nb1 = 1;
+  if (p.nb2 <= 0) p.nb2 = 1;
+  if (!p.a0 || !p.w || !p.out) return SASPA_EINVAL;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return SASPA_EINVAL;
+  if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32) return SASPA_EINVAL;
+  if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return SASPA_EINVAL;
+  if (p.c1 > 0 && !p.a1) return SASPA_EINVAL;
+  if (p.c1 < 0 || p.c0 <= 0) return SASPA_EINVAL;
+  const int epc = p.dtype == SASPA_BF16 ? 8 : 4;
+  if (p.c0 % epc || p.c1 % epc || p.lda0 % epc || (p.c1 > 0 && p.lda1 % epc) || p.ldw % epc) return SASPA_EALIGN;
+  if (p.ldo % 4 || (p.residual && p.ldr % 4)) return SASPA_EALIGN;
+  if (!aligned16(p.a0) || !aligned16(p.w) || !aligned16(p.out) || (p.a1 && !aligned16(p.a1)) ||
+      (p.residual && !aligned16(p.residual)) || (p.bias && !aligned16(p.bias)) || (p.rowvec && !aligned16(p.rowvec)))
+    return SASPA_EALIGN;
+  if (p.sa1 % epc || p.sa2 % epc || p.sw1 % epc || p.sw2 % epc || p.so1 % 4 || p.so2 % 4) return SASPA_EALIGN;
+  if (p.rowvec && (p.ldrv % 4)) return SASPA_EALIGN;
+  if (p.K != p.kh * p.kw * (p.c0 + p.c1)) return SASPA_ERANGE;
+  if ((long long)p.batch * p.hout * p.wout != p.M) return SASPA_ERANGE;
+  if (p.lda0 < p.c0 || (p.c1 > 0 && p.lda1 < p.c1) || p.ldw < p.K || p.ldo < p.N) return SASPA_ERANGE;
+  // the window of every output pixel must come from the declared input extent
+  {
+    const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
+    if ((p.hout - 1) * p.stride - p.pad >= hv || (p.wout - 1) * p.stride - p.pad >= wv) return SASPA_ERANGE;
+  }
+  if ((long long)p.batch * p.hin * p.win >= (1ll << 31)) return SASPA_ERANGE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.dtype == SASPA_BF16) return dispatch<bf16_t>(p, s);
+  return dispatch<float>(p, s);
+}

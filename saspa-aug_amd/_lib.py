@@ -1,0 +1,92 @@
+"""ctypes binding of libsaspa_hip.so (include/saspa_hip.h).  No fallback of any kind."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaspa_hip.so")
+
+SASPA_BF16, SASPA_F32 = 0, 1
+ERRORS = {-1: "SASPA_EINVAL (null pointer / bad size)", -2: "SASPA_EALIGN (16-byte alignment / channel multiple)",
+          -3: "SASPA_ERANGE (unsupported shape)"}
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("a0", C.c_void_p), ("a1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+        ("lda0", C.c_int), ("lda1", C.c_int), ("batch", C.c_int), ("hin", C.c_int), ("win", C.c_int),
+        ("hout", C.c_int), ("wout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
+        ("pad", C.c_int), ("upsample", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int), ("M", C.c_int),
+        ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ldrv", C.c_int),
+        ("residual", C.c_void_p), ("ldr", C.c_int), ("alpha", C.c_float), ("act", C.c_int),
+        ("out", C.c_void_p), ("ldo", C.c_int), ("nb1", C.c_int), ("nb2", C.c_int),
+        ("sa1", C.c_longlong), ("sa2", C.c_longlong), ("sw1", C.c_longlong), ("sw2", C.c_longlong),
+        ("so1", C.c_longlong), ("so2", C.c_longlong),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", C.c_int), ("sqb", C.c_longlong),
+        ("k", C.c_void_p), ("ldk", C.c_int), ("skb", C.c_longlong),
+        ("vt", C.c_void_p), ("ldvt", C.c_int), ("svb", C.c_longlong),
+        ("o", C.c_void_p), ("ldo", C.c_int), ("sob", C.c_longlong),
+        ("batch", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("nq", C.c_int), ("nk", C.c_int),
+        ("scale", C.c_float), ("causal", C.c_int),
+    ]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("x0", C.c_void_p), ("x1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+        ("ldx0", C.c_int), ("ldx1", C.c_int), ("batch", C.c_int), ("hw", C.c_int), ("groups", C.c_int),
+        ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
+        ("nsplit", C.c_int), ("scale_shift", C.c_void_p), ("act", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int),
+    ]
+
+
+# every symbol include/saspa_hip.h declares: (name, restype, argtypes)
+_I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
+SYMBOLS = {
+    "saspa_gemm": (_I, [C.POINTER(GemmParams), _P]),
+    "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
+    "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
+    "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),
+    "saspa_groupnorm_apply": (_I, [C.POINTER(GroupNormParams), _P]),
+    "saspa_layernorm": (_I, [_I, _P, _I, _P, _I, _LL, _I, _P, _P, _F, _P]),
+    "saspa_geglu": (_I, [_I, _P, _I, _P, _I, _LL, _I, _P]),
+    "saspa_activation": (_I, [_I, _I, _P, _I, _P, _I, _LL, _I, _P]),
+    "saspa_embed_tokens": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "saspa_cfg_ddim_step": (_I, [_I, _P, _P, _I, _LL, _I, _I, _F, _F, _F, _F, _F, _P]),
+    "saspa_scale": (_I, [_I, _P, _P, _LL, _F, _P]),
+    "saspa_u8_to_act": (_I, [_I, _P, _P, _LL, _P]),
+    "saspa_act_to_u8": (_I, [_I, _P, _I, _P, _LL, _P]),
+    "saspa_canny": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "saspa_abi_version": (_I, []),
+    "saspa_build_arch": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the gfx950 kernels are not built. Run "
+            "`make -C saspa-aug_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = ERRORS.get(code, f"hipError_t {code}" if code > 0 else f"error {code}")
+        raise RuntimeError(f"{what}: {msg}")

@@ -1,0 +1,31 @@
+"""Architecture configs of the model families the reference's hot path instantiates
+(run_aug/run_aug.py:53-72 BASE_MODEL_DICT / CONTROLNET_DICT_SD -> HF repo ids; the numbers
+below are those repos' public config.json values)."""
+
+# runwayml/stable-diffusion-v1-5 : unet/config.json.  "heads" is diffusers'
+# attention_head_dim=8, which for this model is the NUMBER of heads (head dim = C/8).
+SD15_UNET = dict(
+    in_channels=4, out_channels=4, block_out=(320, 640, 1280, 1280),
+    attn=(True, True, True, False), layers=2, heads=8, ctx_dim=768, groups=32, temb_dim=1280,
+)
+# lllyasviel/control_v11p_sd15_canny : config.json
+SD15_CONTROLNET = dict(SD15_UNET, cond_channels=3, cond_embed=(16, 32, 96, 256))
+# runwayml/stable-diffusion-v1-5 : vae/config.json (decoder half)
+SD15_VAE = dict(latent_channels=4, out_channels=3, block_out=(128, 256, 512, 512), layers=2, groups=32,
+                scaling_factor=0.18215)
+# openai/clip-vit-large-patch14 text tower (text_encoder/config.json)
+CLIP_L = dict(vocab=49408, width=768, layers=12, heads=12, mlp=3072, max_pos=77)
+
+SD15 = dict(unet=SD15_UNET, controlnet=SD15_CONTROLNET, vae=SD15_VAE, text=CLIP_L)
+
+
+def tiny(width=32, ctx=64, groups=8, heads=4, vae_width=16):
+    """Reduced-width family with the same topology (tests / smoke)."""
+    unet = dict(in_channels=4, out_channels=4, block_out=(width, 2 * width, 4 * width, 4 * width),
+                attn=(True, True, True, False), layers=2, heads=heads, ctx_dim=ctx, groups=groups,
+                temb_dim=4 * width)
+    cn = dict(unet, cond_channels=3, cond_embed=(8, 16, 24, 32))
+    vae = dict(latent_channels=4, out_channels=3, block_out=(vae_width, 2 * vae_width, 4 * vae_width, 4 * vae_width),
+               layers=2, groups=groups, scaling_factor=0.18215)
+    text = dict(vocab=512, width=ctx, layers=2, heads=4, mlp=4 * ctx, max_pos=77)
+    return dict(unet=unet, controlnet=cn, vae=vae, text=text)

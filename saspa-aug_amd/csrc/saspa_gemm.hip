@@ -34,10 +34,14 @@ template <> struct Mma<float> {
   // (4*kk + g), so MFMA step j pairs element j of every group: the k order is a fixed
   // permutation shared by both operands (exact fp32 fma chain per output).
   __device__ static __forceinline__ void run(const u32x4& wf, const u32x4& xf, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.x), __builtin_bit_cast(float, xf.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.y), __builtin_bit_cast(float, xf.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.z), __builtin_bit_cast(float, xf.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, xf.w), acc, 0, 0, 0);
+    // NOTE: bit-cast the WHOLE vector; __builtin_bit_cast(float, vec.x) on an ext-vector
+    // element lvalue silently reads element 0 (hipcc / ROCm 7.2).
+    const f32x4 a = __builtin_bit_cast(f32x4, wf);
+    const f32x4 b = __builtin_bit_cast(f32x4, xf);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
   }
 };
 

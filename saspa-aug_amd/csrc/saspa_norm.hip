@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const SaspaGroupNormPar
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = ss[j]; }
   __syncthreads();
-  // threads 0..cxw*16-1 each reduce one (chunk column, value) over the pixel rows
-  if (tid < cxw * 16) {
-    const int col = tid / 16, val = tid % 16;
+  // each (chunk column, value) pair is reduced over the pixel rows by one thread
+  for (int wi = tid; wi < cxw * 16; wi += 256) {
+    const int col = wi / 16, val = wi % 16;
     float a = 0.f;
     for (int r = 0; r < rows; ++r) a += red[(r * cxw + col) * 16 + val];
     const int chunk2 = blockIdx.z * cxw + col;

@@ -1,0 +1,480 @@
+"""The diffusers modules the reference's `pipe(...)` call executes (run_aug/run_aug.py:278),
+re-expressed as launch sequences of the gfx950 kernels (saspa_aug_amd.ops).
+
+Layout decisions (MI355X-first, not a translation of diffusers' NCHW modules):
+  * activations are channels-last [B,H,W,C] so a transformer's token matrix [B,HW,C] is the
+    same buffer as the conv feature map -- no permutes anywhere;
+  * every conv / linear is one implicit-GEMM launch with bias, time-embedding row vector,
+    residual add, SiLU and the ControlNet conditioning scale fused in its epilogue;
+  * nearest-x2 upsampling and the skip concat are folded into the conv's A-operand loader;
+  * q,k projections are one fused GEMM; the v projection is computed TRANSPOSED (swapped
+    GEMM operands) so flash attention never transposes; v biases are folded into the
+    out-projection bias (softmax rows sum to 1);
+  * time-invariant work is hoisted out of the step loop: the time-embedding MLP and every
+    resnet's time_emb_proj for ALL steps (one [steps, C] table each), cross-attention K/V
+    per prompt, the ControlNet conditioning embedding per image;
+  * ControlNet residuals are added to the UNet skips inside the ControlNet zero-conv
+    epilogue (residual = UNet skip), so the UNet decoder reads the summed tensors.
+
+Semantics follow [upstream] diffusers 0.32.2 as listed in SURVEY.md 3.2 / 8(a7)."""
+import math
+
+import torch
+
+from . import ops
+from . import weights as W
+
+SILU = ops.ACT_SILU
+
+
+def _f32(t, dev):
+    return t.detach().to(dev, torch.float32).contiguous()
+
+
+class _Packed:
+    """Device-resident, kernel-layout parameters of one network."""
+
+    def __init__(self, sd, dev, dtype):
+        self.sd, self.dev, self.dtype = sd, dev, dtype
+        self.p = {}
+
+    def conv(self, name, split=None):
+        w = self.sd[name + ".weight"]
+        if split is None:
+            pk = W.pack_conv(w)
+        else:
+            c0, c1 = split
+            pk = W.pack_conv_split(w, c0, W.round8(c0), c1, W.round8(c1))
+        self.p[name + ".w"] = pk.to(self.dev, self.dtype)
+        if name + ".bias" in self.sd:
+            self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
+
+    def linear(self, name, dtype=None):
+        self.p[name + ".w"] = W.pack_linear(self.sd[name + ".weight"]).to(self.dev, dtype or self.dtype)
+        if name + ".bias" in self.sd:
+            self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
+
+    def norm(self, name):
+        self.p[name + ".g"] = _f32(self.sd[name + ".weight"], self.dev)
+        self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
+
+    def attn(self, name, self_attn, has_bias=False):
+        """Fused [to_q; to_k] for self-attention, to_v kept separate (consumed as the A
+        operand of the transposed projection); v bias folded into the out bias."""
+        sd = self.sd
+        if self_attn:
+            wq, wk = sd[name + ".to_q.weight"], sd[name + ".to_k.weight"]
+            self.p[name + ".qk.w"] = torch.cat([wq, wk], 0).contiguous().to(self.dev, self.dtype)
+            if has_bias:
+                self.p[name + ".qk.b"] = _f32(torch.cat([sd[name + ".to_q.bias"], sd[name + ".to_k.bias"]]), self.dev)
+        else:
+            self.p[name + ".q.w"] = sd[name + ".to_q.weight"].contiguous().to(self.dev, self.dtype)
+            self.p[name + ".k.w"] = W.pack_linear(sd[name + ".to_k.weight"]).to(self.dev, self.dtype)
+        self.p[name + ".v.w"] = W.pack_linear(sd[name + ".to_v.weight"]).to(self.dev, self.dtype)
+        wo = sd[name + ".to_out.0.weight"]
+        bo = sd[name + ".to_out.0.bias"]
+        if has_bias:
+            bo = bo + wo @ sd[name + ".to_v.bias"]
+        self.p[name + ".o.w"] = wo.contiguous().to(self.dev, self.dtype)
+        self.p[name + ".o.b"] = _f32(bo, self.dev)
+
+
+# ------------------------------------------------------------------------------------------
+# attention (shared by UNet / ControlNet / VAE / CLIP)
+# ------------------------------------------------------------------------------------------
+def project_vt(x, wv, nk):
+    """vt[b] = Wv @ x_b^T -> [B, C, ld] with keys contiguous (pad columns zero)."""
+    b, n, k = x.shape
+    c = wv.shape[0]
+    ld = ops.round8(nk)
+    vt = torch.zeros((b, c, ld), device=x.device, dtype=x.dtype)
+    ops.gemm_batched(wv, wv.stride(0), (0, 0), x, x.stride(1), (x.stride(0), 0), vt, ld, (c * ld, 0), c, nk, k, b, 1)
+    return vt
+
+
+def attention_core(q, k, vt, heads, nq, nk, causal=False):
+    """q: [B,nq,C] view, k: [B,nk,C] view, vt: [B,C,ld].  bf16 with head dim <= 160: fused
+    flash kernel; otherwise (fp32 parity mode, 512-wide VAE head): scores GEMM -> row softmax
+    -> PV GEMM, all batched over (batch, head)."""
+    b = q.shape[0]
+    c = vt.shape[1]
+    d = c // heads
+    out = torch.empty((b, nq, c), device=q.device, dtype=q.dtype)
+    scale = d ** -0.5
+    if q.dtype == torch.bfloat16 and d <= 160:
+        return ops.flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal)
+    lds = ops.round8(nk)
+    assert vt.stride(1) >= lds
+    scores = torch.empty((b, heads, nq, lds), device=q.device, dtype=q.dtype)
+    ops.gemm_batched(q, q.stride(1), (q.stride(0), d), k, k.stride(1), (k.stride(0), d), scores, lds,
+                     (heads * nq * lds, nq * lds), nq, nk, d, b, heads)
+    ops.softmax_rows(scores, nk, scale, causal, nq)
+    ops.gemm_batched(scores, lds, (heads * nq * lds, nq * lds), vt, vt.stride(1), (vt.stride(0), d * vt.stride(1)), out, c,
+                     (nq * c, d), nq, d, lds, b, heads)
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# UNet / ControlNet building blocks
+# ------------------------------------------------------------------------------------------
+class _Net:
+    def __init__(self, sd, cfg, dev, dtype):
+        self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        self.pk = _Packed(sd, dev, dtype)
+        self.p = self.pk.p
+        self.temb_tables = {}
+
+    # ---- packing helpers ----
+    def _pack_resnet(self, pfx, split=None):
+        pk = self.pk
+        pk.norm(pfx + ".norm1")
+        pk.conv(pfx + ".conv1")
+        pk.norm(pfx + ".norm2")
+        pk.conv(pfx + ".conv2")
+        if pfx + ".conv_shortcut.weight" in pk.sd:
+            pk.conv(pfx + ".conv_shortcut", split)
+        if pfx + ".time_emb_proj.weight" in pk.sd:
+            pk.linear(pfx + ".time_emb_proj", torch.float32)
+            self.resnets_with_temb.append(pfx)
+
+    def _pack_transformer(self, pfx):
+        pk = self.pk
+        pk.norm(pfx + ".norm")
+        pk.conv(pfx + ".proj_in")
+        t = pfx + ".transformer_blocks.0"
+        for n in ("norm1", "norm2", "norm3"):
+            pk.norm(f"{t}.{n}")
+        pk.attn(t + ".attn1", True)
+        pk.attn(t + ".attn2", False)
+        pk.linear(t + ".ff.net.0.proj")
+        pk.linear(t + ".ff.net.2")
+        pk.conv(pfx + ".proj_out")
+        self.transformers.append(pfx)
+
+    def _pack_encoder(self):
+        cfg, pk = self.cfg, self.pk
+        self.resnets_with_temb, self.transformers = [], []
+        pk.conv("conv_in")
+        pk.linear("time_embedding.linear_1", torch.float32)
+        pk.linear("time_embedding.linear_2", torch.float32)
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"]):
+                self._pack_resnet(f"down_blocks.{i}.resnets.{j}")
+                if cfg["attn"][i]:
+                    self._pack_transformer(f"down_blocks.{i}.attentions.{j}")
+            if i != n_lvl - 1:
+                pk.conv(f"down_blocks.{i}.downsamplers.0.conv")
+        self._pack_resnet("mid_block.resnets.0")
+        self._pack_transformer("mid_block.attentions.0")
+        self._pack_resnet("mid_block.resnets.1")
+
+    # ---- hoisted, time-invariant state ----
+    def prepare_timesteps(self, timesteps):
+        """Time-embedding MLP and every resnet's time_emb_proj for ALL steps (fp32 GEMMs):
+        table[pfx] = [steps, Cout].  The sinusoid is host scheduler state, like the DDIM
+        coefficients (Timesteps(dim0, flip_sin_to_cos=True, freq_shift=0))."""
+        dim0 = self.cfg["block_out"][0]
+        half = dim0 // 2
+        t = torch.as_tensor(timesteps, dtype=torch.float32)
+        exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+        ang = t[:, None] * torch.exp(exponent)[None, :]
+        sinus = torch.cat([torch.cos(ang), torch.sin(ang)], -1).to(self.dev)
+        p = self.p
+        e = ops.linear(sinus, p["time_embedding.linear_1.w"], p["time_embedding.linear_1.b"], act=SILU)
+        e = ops.linear(e, p["time_embedding.linear_2.w"], p["time_embedding.linear_2.b"])
+        se = ops.activation(e, SILU)
+        self.temb_tables = {pfx: ops.linear(se, p[pfx + ".time_emb_proj.w"], p[pfx + ".time_emb_proj.b"])
+                            for pfx in self.resnets_with_temb}
+
+    def prepare_context(self, ctx):
+        """Cross-attention K and V^T of every transformer block for a [B,77,ctx_dim] batch."""
+        b, n, _ = ctx.shape
+        self.ctx_kv = {}
+        for pfx in self.transformers:
+            a = pfx + ".transformer_blocks.0.attn2"
+            k = ops.linear(ctx, self.p[a + ".k.w"])                     # [B,77,C]
+            vt = project_vt(ctx, self.p[a + ".v.w"], n)                 # [B,C,80]
+            self.ctx_kv[pfx] = (k, vt, n)
+
+    # ---- blocks ----
+    def resnet(self, pfx, x, step, eps, x2=None):
+        p, g = self.p, self.cfg["groups"]
+        rv = self.temb_tables[pfx][step] if pfx in self.temb_tables else None
+        h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
+        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv)
+        h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU)
+        if pfx + ".conv_shortcut.w" in p:
+            sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"], x2=x2)
+        else:
+            assert x2 is None
+            sc = x
+        return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
+
+    def transformer(self, pfx, x):
+        p, g, heads = self.p, self.cfg["groups"], self.cfg["heads"]
+        b, hh, ww, c = x.shape
+        n = hh * ww
+        t = pfx + ".transformer_blocks.0"
+        h = ops.groupnorm(x, p[pfx + ".norm.g"], p[pfx + ".norm.b"], g, 1e-6)
+        h = ops.conv(h, p[pfx + ".proj_in.w"], p[pfx + ".proj_in.b"]).view(b, n, c)
+        # self-attention
+        n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
+        qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
+        vt = project_vt(n1, p[t + ".attn1.v.w"], n)
+        o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n)
+        h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
+        # cross-attention against the cached text K / V^T
+        n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
+        q = ops.linear(n2, p[t + ".attn2.q.w"])
+        k, vtc, nk = self.ctx_kv[pfx]
+        o = attention_core(q, k, vtc, heads, n, nk)
+        h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
+        # GEGLU feed-forward
+        n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
+        ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
+        h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
+        return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x)
+
+    def encode(self, sample, step, conv_in_residual=None):
+        """conv_in + down blocks + mid block.  Returns (mid, [skips])."""
+        cfg, p = self.cfg, self.p
+        s = ops.conv(sample, p["conv_in.w"], p["conv_in.b"], kh=3, kw=3, pad=1, residual=conv_in_residual)
+        skips = [s]
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"]):
+                s = self.resnet(f"down_blocks.{i}.resnets.{j}", s, step, 1e-5)
+                if cfg["attn"][i]:
+                    s = self.transformer(f"down_blocks.{i}.attentions.{j}", s)
+                skips.append(s)
+            if i != n_lvl - 1:
+                d = f"down_blocks.{i}.downsamplers.0.conv"
+                s = ops.conv(s, p[d + ".w"], p[d + ".b"], kh=3, kw=3, stride=2, pad=1)
+                skips.append(s)
+        s = self.resnet("mid_block.resnets.0", s, step, 1e-5)
+        s = self.transformer("mid_block.attentions.0", s)
+        s = self.resnet("mid_block.resnets.1", s, step, 1e-5)
+        return s, skips
+
+
+class UNet(_Net):
+    """UNet2DConditionModel (SD-1.5 topology)."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        super().__init__(sd, cfg, dev, dtype)
+        self._pack_encoder()
+        pk = self.pk
+        bo = cfg["block_out"]
+        # skip channel bookkeeping (mirrors the encoder)
+        skip_ch = [bo[0]]
+        for i, c in enumerate(bo):
+            skip_ch += [c] * cfg["layers"]
+            if i != len(bo) - 1:
+                skip_ch.append(c)
+        rev = list(reversed(bo))
+        prev = rev[0]
+        n_lvl = len(bo)
+        for i, c in enumerate(rev):
+            for j in range(cfg["layers"] + 1):
+                sk = skip_ch.pop()
+                self._pack_resnet(f"up_blocks.{i}.resnets.{j}", split=(prev, sk))
+                if list(reversed(cfg["attn"]))[i]:
+                    self._pack_transformer(f"up_blocks.{i}.attentions.{j}")
+                prev = c
+            if i != n_lvl - 1:
+                pk.conv(f"up_blocks.{i}.upsamplers.0.conv")
+        pk.norm("conv_norm_out")
+        pk.conv("conv_out")
+        pk.sd = None  # drop the fp32 host copy reference
+
+    def decode(self, mid, skips, step, out=None):
+        cfg, p = self.cfg, self.p
+        s = mid
+        skips = list(skips)
+        n_lvl = len(cfg["block_out"])
+        rev_attn = list(reversed(cfg["attn"]))
+        for i in range(n_lvl):
+            for j in range(cfg["layers"] + 1):
+                sk = skips.pop()
+                s = self.resnet(f"up_blocks.{i}.resnets.{j}", s, step, 1e-5, x2=sk)
+                if rev_attn[i]:
+                    s = self.transformer(f"up_blocks.{i}.attentions.{j}", s)
+            if i != n_lvl - 1:
+                u = f"up_blocks.{i}.upsamplers.0.conv"
+                s = ops.conv(s, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True)
+        s = ops.groupnorm(s, p["conv_norm_out.g"], p["conv_norm_out.b"], cfg["groups"], 1e-5, SILU)
+        return ops.conv(s, p["conv_out.w"], p["conv_out.b"], kh=3, kw=3, pad=1, out=out)
+
+    def forward(self, sample, step, down_residuals=None, mid_residual=None):
+        """Plain UNet forward (tests): residuals are added with an identity 'conv'-free path."""
+        mid, skips = self.encode(sample, step)
+        if down_residuals is not None:
+            skips = [a + b for a, b in zip(skips, down_residuals)]   # test-only host add
+            mid = mid + mid_residual
+        return self.decode(mid, skips, step)
+
+
+class ControlNet(_Net):
+    """ControlNetModel (control_v11p_sd15_canny topology)."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        super().__init__(sd, cfg, dev, dtype)
+        self._pack_encoder()
+        pk = self.pk
+        ce = cfg["cond_embed"]
+        e = "controlnet_cond_embedding"
+        pk.conv(e + ".conv_in")
+        for i in range(2 * (len(ce) - 1)):
+            pk.conv(f"{e}.blocks.{i}")
+        pk.conv(e + ".conv_out")
+        n_skips = 1 + sum(cfg["layers"] + (1 if i != len(cfg["block_out"]) - 1 else 0) for i in range(len(cfg["block_out"])))
+        self.n_skips = n_skips
+        for i in range(n_skips):
+            pk.conv(f"controlnet_down_blocks.{i}")
+        pk.conv("controlnet_mid_block")
+        pk.sd = None
+
+    def cond_embedding(self, cond):
+        """ControlNetConditioningEmbedding on [B,H,W,8] control images in [0,1]; time-invariant,
+        computed once per image (diffusers recomputes it every step)."""
+        p = self.p
+        e = "controlnet_cond_embedding"
+        h = ops.conv(cond, p[e + ".conv_in.w"], p[e + ".conv_in.b"], kh=3, kw=3, pad=1, act=SILU)
+        for i in range(len(self.cfg["cond_embed"]) - 1):
+            h = ops.conv(h, p[f"{e}.blocks.{2 * i}.w"], p[f"{e}.blocks.{2 * i}.b"], kh=3, kw=3, pad=1, act=SILU)
+            h = ops.conv(h, p[f"{e}.blocks.{2 * i + 1}.w"], p[f"{e}.blocks.{2 * i + 1}.b"], kh=3, kw=3, stride=2, pad=1,
+                         act=SILU)
+        return ops.conv(h, p[e + ".conv_out.w"], p[e + ".conv_out.b"], kh=3, kw=3, pad=1)
+
+    def forward(self, sample, step, cond_emb, scale, unet_skips=None, unet_mid=None):
+        """Returns ([12 residuals], mid residual), each scale*(zero_conv(feature)) and, when the
+        UNet encoder outputs are given, already summed with them (fused epilogue)."""
+        p = self.p
+        mid, feats = self.encode(sample, step, conv_in_residual=cond_emb)
+        outs = []
+        for i, f in enumerate(feats):
+            r = None if unet_skips is None else unet_skips[i]
+            outs.append(ops.conv(f, p[f"controlnet_down_blocks.{i}.w"], p[f"controlnet_down_blocks.{i}.b"], alpha=scale,
+                                 residual=r))
+        m = ops.conv(mid, p["controlnet_mid_block.w"], p["controlnet_mid_block.b"], alpha=scale, residual=unet_mid)
+        return outs, m
+
+
+class VAEDecoder:
+    """AutoencoderKL.decode."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        pk = self.pk = _Packed(sd, dev, dtype)
+        self.p = pk.p
+        pk.conv("post_quant_conv")
+        pk.conv("decoder.conv_in")
+        self._pack_resnet("decoder.mid_block.resnets.0")
+        a = "decoder.mid_block.attentions.0"
+        pk.norm(a + ".group_norm")
+        pk.attn(a, True, has_bias=True)
+        self._pack_resnet("decoder.mid_block.resnets.1")
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"] + 1):
+                self._pack_resnet(f"decoder.up_blocks.{i}.resnets.{j}")
+            if i != n_lvl - 1:
+                pk.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv")
+        pk.norm("decoder.conv_norm_out")
+        pk.conv("decoder.conv_out")
+        pk.sd = None
+
+    def _pack_resnet(self, pfx):
+        pk = self.pk
+        pk.norm(pfx + ".norm1")
+        pk.conv(pfx + ".conv1")
+        pk.norm(pfx + ".norm2")
+        pk.conv(pfx + ".conv2")
+        if pfx + ".conv_shortcut.weight" in pk.sd:
+            pk.conv(pfx + ".conv_shortcut")
+
+    def resnet(self, pfx, x):
+        p, g = self.p, self.cfg["groups"]
+        h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, 1e-6, SILU)
+        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1)
+        h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, 1e-6, SILU)
+        sc = x
+        if pfx + ".conv_shortcut.w" in p:
+            sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"])
+        return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
+
+    def mid_attention(self, x):
+        p = self.p
+        a = "decoder.mid_block.attentions.0"
+        b, hh, ww, c = x.shape
+        n = hh * ww
+        h = ops.groupnorm(x, p[a + ".group_norm.g"], p[a + ".group_norm.b"], self.cfg["groups"], 1e-6).view(b, n, c)
+        qk = ops.linear(h, p[a + ".qk.w"], p[a + ".qk.b"])
+        vt = project_vt(h, p[a + ".v.w"], n)
+        o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, 1, n, n)
+        return ops.linear(o, p[a + ".o.w"], p[a + ".o.b"], residual=x.view(b, n, c)).view(b, hh, ww, c)
+
+    def decode(self, z):
+        """z: [B,h,w,8] latents ALREADY divided by the scaling factor -> [B,8h,8w,8] (3 live)."""
+        p, cfg = self.p, self.cfg
+        h = ops.conv(z, p["post_quant_conv.w"], p["post_quant_conv.b"])
+        h = ops.conv(h, p["decoder.conv_in.w"], p["decoder.conv_in.b"], kh=3, kw=3, pad=1)
+        h = self.resnet("decoder.mid_block.resnets.0", h)
+        h = self.mid_attention(h)
+        h = self.resnet("decoder.mid_block.resnets.1", h)
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"] + 1):
+                h = self.resnet(f"decoder.up_blocks.{i}.resnets.{j}", h)
+            if i != n_lvl - 1:
+                u = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                h = ops.conv(h, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True)
+        h = ops.groupnorm(h, p["decoder.conv_norm_out.g"], p["decoder.conv_norm_out.b"], cfg["groups"], 1e-6, SILU)
+        return ops.conv(h, p["decoder.conv_out.w"], p["decoder.conv_out.b"], kh=3, kw=3, pad=1)
+
+
+class CLIPText:
+    """CLIPTextModel text tower: last_hidden_state after the final LayerNorm."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        pk = self.pk = _Packed(sd, dev, dtype)
+        p = self.p = pk.p
+        e = "text_model.embeddings"
+        p["tok"] = sd[e + ".token_embedding.weight"].to(dev, dtype).contiguous()
+        p["pos"] = sd[e + ".position_embedding.weight"].to(dev, dtype).contiguous()
+        for i in range(cfg["layers"]):
+            lp = f"text_model.encoder.layers.{i}"
+            a = lp + ".self_attn"
+            p[a + ".qk.w"] = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"]], 0).contiguous().to(dev, dtype)
+            p[a + ".qk.b"] = _f32(torch.cat([sd[a + ".q_proj.bias"], sd[a + ".k_proj.bias"]]), dev)
+            p[a + ".v.w"] = sd[a + ".v_proj.weight"].contiguous().to(dev, dtype)
+            wo = sd[a + ".out_proj.weight"]
+            p[a + ".o.w"] = wo.contiguous().to(dev, dtype)
+            p[a + ".o.b"] = _f32(sd[a + ".out_proj.bias"] + wo @ sd[a + ".v_proj.bias"], dev)
+            pk.norm(lp + ".layer_norm1")
+            pk.norm(lp + ".layer_norm2")
+            pk.linear(lp + ".mlp.fc1")
+            pk.linear(lp + ".mlp.fc2")
+        pk.norm("text_model.final_layer_norm")
+        pk.sd = None
+
+    def forward(self, ids):
+        """ids: int [B,77] (device) -> [B,77,width]"""
+        cfg, p = self.cfg, self.p
+        b, n = ids.shape
+        c = cfg["width"]
+        x = ops.embed_tokens(ids, p["tok"], p["pos"], n).view(b, n, c)
+        for i in range(cfg["layers"]):
+            lp = f"text_model.encoder.layers.{i}"
+            a = lp + ".self_attn"
+            h = ops.layernorm(x, p[lp + ".layer_norm1.g"], p[lp + ".layer_norm1.b"])
+            qk = ops.linear(h, p[a + ".qk.w"], p[a + ".qk.b"])
+            vt = project_vt(h, p[a + ".v.w"], n)
+            o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, cfg["heads"], n, n, causal=True)
+            x = ops.linear(o, p[a + ".o.w"], p[a + ".o.b"], residual=x)
+            h = ops.layernorm(x, p[lp + ".layer_norm2.g"], p[lp + ".layer_norm2.b"])
+            h = ops.activation(ops.linear(h, p[lp + ".mlp.fc1.w"], p[lp + ".mlp.fc1.b"]), ops.ACT_QUICK_GELU)
+            x = ops.linear(h, p[lp + ".mlp.fc2.w"], p[lp + ".mlp.fc2.b"], residual=x)
+        return ops.layernorm(x, p["text_model.final_layer_norm.g"], p["text_model.final_layer_norm.b"])

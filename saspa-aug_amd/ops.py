@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C ABI (include/saspa_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every function here
+enqueues hand-written gfx950 kernels through ctypes and does no arithmetic of its own.
+Activations are channels-last ``[B, H, W, C]`` (or ``[M, C]`` token matrices) whose last
+dim is contiguous; the pixel pitch (``stride(-2)``) may exceed C (views into wider
+buffers, e.g. the q/k slices of a fused projection)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SILU = 0, 1
+ACT_QUICK_GELU = 2  # saspa_activation only
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return _lib.SASPA_BF16
+    if t.dtype == torch.float32:
+        return _lib.SASPA_F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("saspa_aug_amd ops run on the GPU only (tensor is on %s)" % t.device)
+
+
+def _pitch4(x):
+    """[B,H,W,C] channels-last view -> pixel pitch; validates regular pixel rows."""
+    b, h, w, c = x.shape
+    if c > 1 and x.stride(3) != 1:
+        raise ValueError("last dim must be contiguous")
+    ld = x.stride(2)
+    if ld < c:
+        raise ValueError("pixel pitch smaller than the channel count")
+    if h > 1 and x.stride(1) != w * ld:
+        raise ValueError("rows must be densely packed at the pixel pitch")
+    if b > 1 and x.stride(0) != h * w * ld:
+        raise ValueError("batch images must be densely packed at the pixel pitch")
+    return ld
+
+
+def round8(n):
+    return (n + 7) // 8 * 8
+
+
+def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None):
+    """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
+    ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
+    (pad channels zero)."""
+    _check_dev(x, w, bias, x2, rowvec, residual, out)
+    lib = _lib.load()
+    b, h, wd, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    hv, wv = (2 * h, 2 * wd) if upsample else (h, wd)
+    ho = (hv + 2 * pad - kh) // stride + 1
+    wo = (wv + 2 * pad - kw) // stride + 1
+    n = w.shape[0] if n_out is None else n_out
+    if out is None:
+        nc = round8(n)
+        out = (torch.zeros if nc != n else torch.empty)((b, ho, wo, nc), device=x.device, dtype=x.dtype)
+    p = _lib.GemmParams()
+    p.dtype = _dt(x)
+    p.a0, p.a1 = _ptr(x), _ptr(x2)
+    p.c0, p.c1 = c0, c1
+    p.lda0 = _pitch4(x)
+    p.lda1 = 0 if x2 is None else _pitch4(x2)
+    p.batch, p.hin, p.win, p.hout, p.wout = b, h, wd, ho, wo
+    p.kh, p.kw, p.stride, p.pad, p.upsample = kh, kw, stride, pad, int(upsample)
+    p.w, p.ldw = _ptr(w), w.stride(0)
+    p.M, p.N, p.K = b * ho * wo, n, kh * kw * (c0 + c1)
+    p.bias = _ptr(bias)
+    p.rowvec = _ptr(rowvec)
+    p.ldrv = 0 if (rowvec is None or rowvec.dim() == 1 or rowvec.shape[0] == 1) else rowvec.stride(0)
+    p.residual = _ptr(residual)
+    p.ldr = 0 if residual is None else _pitch4(residual)
+    p.alpha, p.act = float(alpha), int(act)
+    p.out, p.ldo = _ptr(out), _pitch4(out)
+    p.nb1 = p.nb2 = 1
+    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)")
+    return out
+
+
+def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None):
+    """x: [..., K] (last dim contiguous, uniform row pitch) @ w[N, K]^T -> [..., round8(N)]."""
+    _check_dev(x, w, bias, residual, out)
+    lib = _lib.load()
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k) if x.dim() != 2 else x
+    m = x2.shape[0]
+    n = w.shape[0]
+    if out is None:
+        nc = round8(n)
+        out = (torch.zeros if nc != n else torch.empty)((m, nc), device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, out.shape[-1]) if out.dim() != 2 else out
+    r2 = None if residual is None else (residual.reshape(-1, residual.shape[-1]) if residual.dim() != 2 else residual)
+    p = _lib.GemmParams()
+    p.dtype = _dt(x)
+    p.a0, p.a1, p.c0, p.c1 = _ptr(x2), None, k, 0
+    p.lda0, p.lda1 = (x2.stride(0) if m > 1 else max(k, x2.stride(0))), 0
+    p.batch, p.hin, p.win, p.hout, p.wout = 1, m, 1, m, 1
+    p.kh = p.kw = p.stride = 1
+    p.pad = p.upsample = 0
+    p.w, p.ldw = _ptr(w), w.stride(0)
+    p.M, p.N, p.K = m, n, k
+    p.bias, p.rowvec, p.ldrv = _ptr(bias), _ptr(rowvec), 0
+    p.residual = _ptr(r2)
+    p.ldr = 0 if r2 is None else (r2.stride(0) if m > 1 else max(n, r2.stride(0)))
+    p.alpha, p.act = float(alpha), int(act)
+    p.out = _ptr(o2)
+    p.ldo = o2.stride(0) if m > 1 else max(n, o2.stride(0))
+    p.nb1 = p.nb2 = 1
+    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)")
+    if x.dim() != 2 and out.dim() == 2:
+        return out.reshape(*x.shape[:-1], out.shape[-1])
+    return out
+
+
+def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=1.0):
+    """Raw batched GEMM out[z] = alpha * a[z] @ w[z]^T; s* = (stride1, stride2) in elements.
+    ``a``/``w``/``out`` are tensors whose data_ptr is the z=0 origin."""
+    _check_dev(a, w, out)
+    lib = _lib.load()
+    p = _lib.GemmParams()
+    p.dtype = _dt(a)
+    p.a0, p.a1, p.c0, p.c1, p.lda0, p.lda1 = _ptr(a), None, k, 0, lda, 0
+    p.batch, p.hin, p.win, p.hout, p.wout = 1, m, 1, m, 1
+    p.kh = p.kw = p.stride = 1
+    p.pad = p.upsample = 0
+    p.w, p.ldw = _ptr(w), ldw
+    p.M, p.N, p.K = m, n, k
+    p.bias = p.rowvec = p.residual = None
+    p.ldrv = p.ldr = 0
+    p.alpha, p.act = float(alpha), 0
+    p.out, p.ldo = _ptr(out), ldo
+    p.nb1, p.nb2 = nb1, nb2
+    p.sa1, p.sa2 = sa
+    p.sw1, p.sw2 = sw
+    p.so1, p.so2 = so
+    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)")
+    return out
+
+
+def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False):
+    """q: [B, nq, >=heads*d] view, k: [B, nk, >=heads*d] view, vt: [B, heads*d, ldvt] (keys
+    contiguous), out: [B, nq, >=heads*d] view.  bf16 only."""
+    _check_dev(q, k, vt, out)
+    lib = _lib.load()
+    if q.dtype != torch.bfloat16:
+        raise TypeError("flash_attn is the bf16 path; fp32 uses the unfused GEMM+softmax path")
+    p = _lib.AttnParams()
+    p.q, p.ldq, p.sqb = _ptr(q), q.stride(1), q.stride(0)
+    p.k, p.ldk, p.skb = _ptr(k), k.stride(1), k.stride(0)
+    p.vt, p.ldvt, p.svb = _ptr(vt), vt.stride(1), vt.stride(0)
+    p.o, p.ldo, p.sob = _ptr(out), out.stride(1), out.stride(0)
+    p.batch, p.heads, p.D, p.nq, p.nk = q.shape[0], heads, d, nq, nk
+    p.scale, p.causal = float(scale), int(causal)
+    _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16")
+    return out
+
+
+def softmax_rows(x, n, scale, causal=False, rows_per_mat=1):
+    """In-place softmax(scale*x) over the first n columns of [rows, ld]; pad columns zeroed."""
+    _check_dev(x)
+    lib = _lib.load()
+    x2 = x.view(-1, x.shape[-1])
+    _lib.check(lib.saspa_softmax_rows(_dt(x), _ptr(x2), x2.shape[0], n, x2.stride(0), float(scale), int(causal),
+                                      int(rows_per_mat), _stream()), "saspa_softmax_rows")
+    return x
+
+
+def _gn_nsplit(batch, hw, c8):
+    slabs = (c8 + 31) // 32 if c8 >= 32 else 1
+    want = max(1, 1024 // max(1, batch * slabs))
+    return max(1, min(want, 256, hw // 16 if hw >= 16 else 1))
+
+
+def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
+    """GroupNorm(+SiLU) over channels-last x (optionally concatenated with x2) -> [B,H,W,C]."""
+    _check_dev(x, gamma, beta, x2, out)
+    lib = _lib.load()
+    b, h, w, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    ctot = c0 + c1
+    if out is None:
+        out = torch.empty((b, h, w, ctot), device=x.device, dtype=x.dtype)
+    nsplit = _gn_nsplit(b, h * w, ctot // 8)
+    partial = torch.empty((b * nsplit * ctot * 2,), device=x.device, dtype=torch.float32)
+    ss = torch.empty((b, 2, ctot), device=x.device, dtype=torch.float32)
+    p = _lib.GroupNormParams()
+    p.dtype = _dt(x)
+    p.x0, p.x1, p.c0, p.c1 = _ptr(x), _ptr(x2), c0, c1
+    p.ldx0 = _pitch4(x)
+    p.ldx1 = 0 if x2 is None else _pitch4(x2)
+    p.batch, p.hw, p.groups, p.eps = b, h * w, groups, float(eps)
+    p.gamma, p.beta = _ptr(gamma), _ptr(beta)
+    p.partial, p.nsplit, p.scale_shift = _ptr(partial), nsplit, _ptr(ss)
+    p.act, p.y, p.ldy = int(act), _ptr(out), _pitch4(out)
+    s = _stream()
+    _lib.check(lib.saspa_groupnorm_stats(C.byref(p), s), "saspa_groupnorm_stats")
+    _lib.check(lib.saspa_groupnorm_apply(C.byref(p), s), "saspa_groupnorm_apply")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _check_dev(x, gamma, beta, out)
+    lib = _lib.load()
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, c)
+    rows = x2.shape[0]
+    _lib.check(lib.saspa_layernorm(_dt(x), _ptr(x2), x2.stride(0) if rows > 1 else c, _ptr(o2),
+                                   o2.stride(0) if rows > 1 else c, rows, c, _ptr(gamma), _ptr(beta), float(eps),
+                                   _stream()), "saspa_layernorm")
+    return out
+
+
+def geglu(x, out=None):
+    """x: [..., 2F] -> [..., F] = x[..., :F] * gelu_erf(x[..., F:])"""
+    _check_dev(x, out)
+    lib = _lib.load()
+    f = x.shape[-1] // 2
+    x2 = x.reshape(-1, 2 * f)
+    if out is None:
+        out = torch.empty((*x.shape[:-1], f), device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, f)
+    _lib.check(lib.saspa_geglu(_dt(x), _ptr(x2), x2.stride(0), _ptr(o2), o2.stride(0), x2.shape[0], f, _stream()),
+               "saspa_geglu")
+    return out
+
+
+def activation(x, act, out=None):
+    _check_dev(x, out)
+    lib = _lib.load()
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, c)
+    rows = x2.shape[0]
+    _lib.check(lib.saspa_activation(_dt(x), int(act), _ptr(x2), x2.stride(0) if rows > 1 else c, _ptr(o2),
+                                    o2.stride(0) if rows > 1 else c, rows, c, _stream()), "saspa_activation")
+    return out
+
+
+def embed_tokens(ids, tok, pos, npos):
+    _check_dev(ids, tok, pos)
+    lib = _lib.load()
+    n = ids.numel()
+    c = tok.shape[1]
+    out = torch.empty((n, c), device=tok.device, dtype=tok.dtype)
+    ids32 = ids.reshape(-1).to(torch.int32)
+    _lib.check(lib.saspa_embed_tokens(_dt(tok), _ptr(ids32), n, npos, _ptr(tok), _ptr(pos), c, _ptr(out), _stream()),
+               "saspa_embed_tokens")
+    return out
+
+
+def cfg_ddim_step(eps, x, nimg, hw, c, guidance, sa_t, s1m_t, sa_p, s1m_p):
+    """eps, x: [2*nimg, hw, 8]; updates x (both CFG halves) in place."""
+    _check_dev(eps, x)
+    lib = _lib.load()
+    _lib.check(lib.saspa_cfg_ddim_step(_dt(x), _ptr(eps), _ptr(x), nimg, hw, c, 8, float(guidance), float(sa_t),
+                                       float(s1m_t), float(sa_p), float(s1m_p), _stream()), "saspa_cfg_ddim_step")
+    return x
+
+
+def scale(x, s, out=None):
+    _check_dev(x, out)
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.saspa_scale(_dt(x), _ptr(x), _ptr(out), x.numel(), float(s), _stream()), "saspa_scale")
+    return out
+
+
+def u8_to_act(img_u8, dtype):
+    """u8 [n,H,W,3] -> [n,H,W,8] in [0,1]"""
+    _check_dev(img_u8)
+    lib = _lib.load()
+    n, h, w, _ = img_u8.shape
+    out = torch.empty((n, h, w, 8), device=img_u8.device, dtype=dtype)
+    _lib.check(lib.saspa_u8_to_act(_dt(out), _ptr(img_u8), _ptr(out), n * h * w, _stream()), "saspa_u8_to_act")
+    return out
+
+
+def act_to_u8(x):
+    """[n,H,W,>=4] (3 live channels) -> u8 [n,H,W,3]"""
+    _check_dev(x)
+    lib = _lib.load()
+    n, h, w, _ = x.shape
+    out = torch.empty((n, h, w, 3), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.saspa_act_to_u8(_dt(x), _ptr(x), _pitch4(x), _ptr(out), n * h * w, _stream()), "saspa_act_to_u8")
+    return out
+
+
+def canny(img_u8, low, high):
+    """u8 [n,H,W,3] (device) -> u8 [n,H,W,3] in {0,255}"""
+    _check_dev(img_u8)
+    lib = _lib.load()
+    n, h, w, c = img_u8.shape
+    if c != 3 or img_u8.dtype != torch.uint8 or not img_u8.is_contiguous():
+        raise ValueError("canny expects a contiguous u8 [n,H,W,3] tensor")
+    out = torch.empty_like(img_u8)
+    work = torch.empty((8 * n * h * w,), device=img_u8.device, dtype=torch.uint8)
+    _lib.check(lib.saspa_canny(_ptr(img_u8), _ptr(out), _ptr(work), n, h, w, int(low), int(high), _stream()),
+               "saspa_canny")
+    return out

@@ -1,0 +1,217 @@
+"""Weights: diffusers-named state dicts (synthetic or from safetensors) and their packing
+into the device layout the kernels consume.
+
+The reference loads HF checkpoints (`from_pretrained`, run_aug/run_aug.py:185, :206); there
+is no network / no checkpoint in the build and bench environments, so `synth_*` builds
+architecture-exact tensors under the SAME key names (a real `*.safetensors` loads through
+`load_safetensors` unchanged).  Init: N(0, 1/sqrt(fan_in)) for conv/linear weights, small
+biases, norm gains around 1 -- keeps activations O(1) through 50 steps and avoids
+all-zero MFMA operands."""
+import math
+
+import torch
+
+
+# --------------------------------------------------------------------------------------
+# parameter enumeration (name, shape, kind)
+# --------------------------------------------------------------------------------------
+def _resnet(spec, pfx, cin, cout, temb):
+    spec += [(pfx + ".norm1.weight", (cin,), "gain"), (pfx + ".norm1.bias", (cin,), "bias"),
+             (pfx + ".conv1.weight", (cout, cin, 3, 3), "w"), (pfx + ".conv1.bias", (cout,), "bias")]
+    if temb:
+        spec += [(pfx + ".time_emb_proj.weight", (cout, temb), "w"), (pfx + ".time_emb_proj.bias", (cout,), "bias")]
+    spec += [(pfx + ".norm2.weight", (cout,), "gain"), (pfx + ".norm2.bias", (cout,), "bias"),
+             (pfx + ".conv2.weight", (cout, cout, 3, 3), "w"), (pfx + ".conv2.bias", (cout,), "bias")]
+    if cin != cout:
+        spec += [(pfx + ".conv_shortcut.weight", (cout, cin, 1, 1), "w"), (pfx + ".conv_shortcut.bias", (cout,), "bias")]
+
+
+def _transformer(spec, pfx, c, ctx):
+    spec += [(pfx + ".norm.weight", (c,), "gain"), (pfx + ".norm.bias", (c,), "bias"),
+             (pfx + ".proj_in.weight", (c, c, 1, 1), "w"), (pfx + ".proj_in.bias", (c,), "bias")]
+    t = pfx + ".transformer_blocks.0"
+    for n in ("norm1", "norm2", "norm3"):
+        spec += [(f"{t}.{n}.weight", (c,), "gain"), (f"{t}.{n}.bias", (c,), "bias")]
+    for a, kd in (("attn1", c), ("attn2", ctx)):
+        spec += [(f"{t}.{a}.to_q.weight", (c, c), "w"), (f"{t}.{a}.to_k.weight", (c, kd), "w"),
+                 (f"{t}.{a}.to_v.weight", (c, kd), "w"), (f"{t}.{a}.to_out.0.weight", (c, c), "w"),
+                 (f"{t}.{a}.to_out.0.bias", (c,), "bias")]
+    spec += [(f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"), (f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"),
+             (f"{t}.ff.net.2.weight", (c, 4 * c), "w"), (f"{t}.ff.net.2.bias", (c,), "bias")]
+    spec += [(pfx + ".proj_out.weight", (c, c, 1, 1), "w"), (pfx + ".proj_out.bias", (c,), "bias")]
+
+
+def _encoder(spec, cfg):
+    bo = cfg["block_out"]
+    temb = cfg["temb_dim"]
+    spec += [("conv_in.weight", (bo[0], cfg["in_channels"], 3, 3), "w"), ("conv_in.bias", (bo[0],), "bias"),
+             ("time_embedding.linear_1.weight", (temb, bo[0]), "w"), ("time_embedding.linear_1.bias", (temb,), "bias"),
+             ("time_embedding.linear_2.weight", (temb, temb), "w"), ("time_embedding.linear_2.bias", (temb,), "bias")]
+    cin = bo[0]
+    skip_ch = [bo[0]]
+    for i, c in enumerate(bo):
+        for j in range(cfg["layers"]):
+            _resnet(spec, f"down_blocks.{i}.resnets.{j}", cin, c, temb)
+            if cfg["attn"][i]:
+                _transformer(spec, f"down_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"])
+            cin = c
+            skip_ch.append(c)
+        if i != len(bo) - 1:
+            spec += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (c, c, 3, 3), "w"),
+                     (f"down_blocks.{i}.downsamplers.0.conv.bias", (c,), "bias")]
+            skip_ch.append(c)
+    _resnet(spec, "mid_block.resnets.0", cin, cin, temb)
+    _transformer(spec, "mid_block.attentions.0", cin, cfg["ctx_dim"])
+    _resnet(spec, "mid_block.resnets.1", cin, cin, temb)
+    return skip_ch
+
+
+def unet_spec(cfg):
+    spec = []
+    skip_ch = _encoder(spec, cfg)
+    bo = cfg["block_out"]
+    rev = list(reversed(bo))
+    rev_attn = list(reversed(cfg["attn"]))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(cfg["layers"] + 1):
+            skip = skip_ch.pop()
+            _resnet(spec, f"up_blocks.{i}.resnets.{j}", prev + skip, c, cfg["temb_dim"])
+            if rev_attn[i]:
+                _transformer(spec, f"up_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"])
+            prev = c
+        if i != len(bo) - 1:
+            spec += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (c, c, 3, 3), "w"),
+                     (f"up_blocks.{i}.upsamplers.0.conv.bias", (c,), "bias")]
+    spec += [("conv_norm_out.weight", (bo[0],), "gain"), ("conv_norm_out.bias", (bo[0],), "bias"),
+             ("conv_out.weight", (cfg["out_channels"], bo[0], 3, 3), "w"), ("conv_out.bias", (cfg["out_channels"],), "bias")]
+    return spec
+
+
+def controlnet_spec(cfg):
+    spec = []
+    skip_ch = _encoder(spec, cfg)
+    ce = cfg["cond_embed"]
+    p = "controlnet_cond_embedding"
+    spec += [(p + ".conv_in.weight", (ce[0], cfg["cond_channels"], 3, 3), "w"), (p + ".conv_in.bias", (ce[0],), "bias")]
+    for i in range(len(ce) - 1):
+        spec += [(f"{p}.blocks.{2 * i}.weight", (ce[i], ce[i], 3, 3), "w"), (f"{p}.blocks.{2 * i}.bias", (ce[i],), "bias"),
+                 (f"{p}.blocks.{2 * i + 1}.weight", (ce[i + 1], ce[i], 3, 3), "w"),
+                 (f"{p}.blocks.{2 * i + 1}.bias", (ce[i + 1],), "bias")]
+    bo = cfg["block_out"]
+    spec += [(p + ".conv_out.weight", (bo[0], ce[-1], 3, 3), "w"), (p + ".conv_out.bias", (bo[0],), "bias")]
+    for i, c in enumerate(skip_ch):
+        spec += [(f"controlnet_down_blocks.{i}.weight", (c, c, 1, 1), "w"), (f"controlnet_down_blocks.{i}.bias", (c,), "bias")]
+    spec += [("controlnet_mid_block.weight", (bo[-1], bo[-1], 1, 1), "w"), ("controlnet_mid_block.bias", (bo[-1],), "bias")]
+    return spec
+
+
+def vae_decoder_spec(cfg):
+    spec = []
+    lc = cfg["latent_channels"]
+    bo = cfg["block_out"]
+    top = bo[-1]
+    spec += [("post_quant_conv.weight", (lc, lc, 1, 1), "w"), ("post_quant_conv.bias", (lc,), "bias"),
+             ("decoder.conv_in.weight", (top, lc, 3, 3), "w"), ("decoder.conv_in.bias", (top,), "bias")]
+    _resnet(spec, "decoder.mid_block.resnets.0", top, top, 0)
+    a = "decoder.mid_block.attentions.0"
+    spec += [(a + ".group_norm.weight", (top,), "gain"), (a + ".group_norm.bias", (top,), "bias")]
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        spec += [(f"{a}.{n}.weight", (top, top), "w"), (f"{a}.{n}.bias", (top,), "bias")]
+    _resnet(spec, "decoder.mid_block.resnets.1", top, top, 0)
+    prev = top
+    for i, c in enumerate(reversed(bo)):
+        for j in range(cfg["layers"] + 1):
+            _resnet(spec, f"decoder.up_blocks.{i}.resnets.{j}", prev, c, 0)
+            prev = c
+        if i != len(bo) - 1:
+            spec += [(f"decoder.up_blocks.{i}.upsamplers.0.conv.weight", (c, c, 3, 3), "w"),
+                     (f"decoder.up_blocks.{i}.upsamplers.0.conv.bias", (c,), "bias")]
+    spec += [("decoder.conv_norm_out.weight", (bo[0],), "gain"), ("decoder.conv_norm_out.bias", (bo[0],), "bias"),
+             ("decoder.conv_out.weight", (cfg["out_channels"], bo[0], 3, 3), "w"),
+             ("decoder.conv_out.bias", (cfg["out_channels"],), "bias")]
+    return spec
+
+
+def clip_text_spec(cfg):
+    w = cfg["width"]
+    spec = [("text_model.embeddings.token_embedding.weight", (cfg["vocab"], w), "embed"),
+            ("text_model.embeddings.position_embedding.weight", (cfg["max_pos"], w), "embed")]
+    for i in range(cfg["layers"]):
+        lp = f"text_model.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec += [(f"{lp}.self_attn.{n}.weight", (w, w), "w"), (f"{lp}.self_attn.{n}.bias", (w,), "bias")]
+        spec += [(f"{lp}.layer_norm1.weight", (w,), "gain"), (f"{lp}.layer_norm1.bias", (w,), "bias"),
+                 (f"{lp}.mlp.fc1.weight", (cfg["mlp"], w), "w"), (f"{lp}.mlp.fc1.bias", (cfg["mlp"],), "bias"),
+                 (f"{lp}.mlp.fc2.weight", (w, cfg["mlp"]), "w"), (f"{lp}.mlp.fc2.bias", (w,), "bias"),
+                 (f"{lp}.layer_norm2.weight", (w,), "gain"), (f"{lp}.layer_norm2.bias", (w,), "bias")]
+    spec += [("text_model.final_layer_norm.weight", (w,), "gain"), ("text_model.final_layer_norm.bias", (w,), "bias")]
+    return spec
+
+
+SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec)
+
+
+def synth_state_dict(kind, cfg, seed=0):
+    """Seeded synthetic fp32 state dict with diffusers key names."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape, k in SPECS[kind](cfg):
+        if k == "w":
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) * (1.0 / math.sqrt(fan_in))
+        elif k == "gain":
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif k == "bias":
+            t = 0.05 * torch.randn(shape, generator=g)
+        else:  # embeddings
+            t = 0.5 * torch.randn(shape, generator=g)
+        sd[name] = t
+    return sd
+
+
+def synth_family(cfgs, seed=0):
+    return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(("unet", "controlnet", "vae", "text"))}
+
+
+def load_safetensors(path):
+    """Read a diffusers `*.safetensors` checkpoint into an fp32 state dict."""
+    from safetensors.torch import load_file
+    return {k: v.float() for k, v in load_file(path).items()}
+
+
+# --------------------------------------------------------------------------------------
+# packing into the kernel layout
+# --------------------------------------------------------------------------------------
+def round8(n):
+    return (n + 7) // 8 * 8
+
+
+def pack_conv(w, cin_pad=None):
+    """[Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin_pad] with K index (ky*kw+kx)*Cin_pad + c."""
+    co, ci, kh, kw = w.shape
+    cp = round8(ci) if cin_pad is None else cin_pad
+    t = w.permute(0, 2, 3, 1)
+    if cp != ci:
+        t = torch.nn.functional.pad(t, (0, cp - ci))
+    return t.reshape(co, kh * kw * cp).contiguous()
+
+
+def pack_conv_split(w, c0, c0_pad, c1, c1_pad):
+    """Conv over a channel concat [src0 (c0) | src1 (c1)] whose sources are stored padded."""
+    co, ci, kh, kw = w.shape
+    assert ci == c0 + c1
+    t = w.permute(0, 2, 3, 1)
+    a = torch.nn.functional.pad(t[..., :c0], (0, c0_pad - c0))
+    b = torch.nn.functional.pad(t[..., c0:], (0, c1_pad - c1))
+    return torch.cat([a, b], -1).reshape(co, kh * kw * (c0_pad + c1_pad)).contiguous()
+
+
+def pack_linear(w, k_pad=None):
+    n, k = w.shape
+    kp = round8(k) if k_pad is None else k_pad
+    if kp != k:
+        w = torch.nn.functional.pad(w, (0, kp - k))
+    return w.contiguous()

@@ -1,0 +1,334 @@
+"""GPU parity tests of every HIP kernel, through the C ABI (saspa_aug_amd.ops -> ctypes ->
+libsaspa_hip.so), against plain PyTorch fp32 CPU references of the same op.
+bf16 runs compare against the reference evaluated on bf16-rounded inputs; fp32 runs bound
+accumulation-order error only (tolerances: tests/util.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import saspa_aug_amd  # noqa: F401
+from saspa_aug_amd import ops
+from saspa_aug_amd import weights as W
+from tests.util import assert_close, from_nhwc, q, to_nhwc
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------ linear / GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,k,n", [(300, 320, 960), (77, 768, 320), (1, 320, 1280), (129, 64, 40), (4096, 1280, 320)])
+def test_linear(dev, dtype, m, k, n):
+    x = q(_rand(m, k, seed=1), dtype)
+    w = q(_rand(n, k, seed=2, scale=1 / math.sqrt(k)), dtype)
+    b = _rand(n, seed=3)
+    res = q(_rand(m, n, seed=4), dtype)
+    ref = F.silu((x @ w.t() + b) * 0.75) + res
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev), residual=res.to(dev, dtype), alpha=0.75,
+                     act=ops.ACT_SILU)
+    assert out.shape == (m, ops.round8(n))
+    assert_close(out.float().cpu()[:, :n], ref, dtype, what=f"linear {m}x{k}x{n}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_identity_asymmetric(dev, dtype):
+    """A = I with an asymmetric B catches a transposed C write or swapped operands."""
+    n = 64
+    x = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97 - 48  # exact in bf16
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype))
+    assert torch.equal(out.float().cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_strided_views(dev, dtype):
+    """q/k slices of a fused projection buffer: pitch > K for A, pitch > N for out."""
+    m, k, n = 200, 64, 72
+    big = q(_rand(m, 3 * k, seed=5), dtype)
+    w = q(_rand(n, k, seed=6, scale=0.1), dtype)
+    xd = big.to(dev, dtype)
+    outbuf = torch.zeros(m, 2 * n + 16, device=dev, dtype=dtype)
+    ops.linear(xd[:, k:2 * k], w.to(dev, dtype), out=outbuf[:, 8:8 + n])
+    ref = big[:, k:2 * k] @ w.t()
+    assert_close(outbuf.float().cpu()[:, 8:8 + n], ref, dtype, what="strided linear")
+    assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 8 + n:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # (B, H, W, Cin, Cout, k, stride, upsample)
+    (2, 16, 16, 64, 96, 3, 1, False),
+    (2, 16, 16, 64, 64, 3, 2, False),
+    (1, 8, 12, 32, 48, 3, 1, True),
+    (2, 9, 7, 16, 24, 3, 1, False),      # ragged M, small channel counts
+    (2, 16, 16, 4, 320, 3, 1, False),    # conv_in: Cin=4 padded to 8
+    (2, 16, 16, 64, 4, 3, 1, False),     # conv_out: N=4
+    (1, 16, 16, 32, 3, 3, 1, False),     # VAE conv_out: N=3 (scalar tail)
+    (2, 8, 8, 128, 128, 1, 1, False),    # 1x1
+    (2, 32, 32, 3, 16, 3, 1, False),     # cond-embedding conv_in
+    (2, 32, 32, 16, 32, 3, 2, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv(dev, dtype, case):
+    b, h, w_, cin, cout, k, stride, up = case
+    x = q(_rand(b, cin, h, w_, seed=7), dtype)
+    wt = q(_rand(cout, cin, k, k, seed=8, scale=1 / math.sqrt(cin * k * k)), dtype)
+    bias = _rand(cout, seed=9)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, wt, bias, stride=stride, padding=k // 2)
+    xd = to_nhwc(x, dtype, dev, cpad=W.round8(cin))
+    wd = W.pack_conv(wt).to(dev, dtype)
+    out = ops.conv(xd, wd, bias.to(dev), kh=k, kw=k, stride=stride, pad=k // 2, upsample=up)
+    assert out.shape == (b, ref.shape[2], ref.shape[3], ops.round8(cout))
+    assert_close(from_nhwc(out, cout), ref, dtype, what=f"conv {case}")
+    if ops.round8(cout) != cout:
+        assert out[..., cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_concat_rowvec_residual(dev, dtype):
+    """Up-block resnet conv1: two-source concat + time-embedding row vector; conv2: residual."""
+    b, h, w_, c0, c1, cout = 2, 8, 8, 64, 32, 64
+    x0 = q(_rand(b, c0, h, w_, seed=10), dtype)
+    x1 = q(_rand(b, c1, h, w_, seed=11), dtype)
+    wt = q(_rand(cout, c0 + c1, 3, 3, seed=12, scale=0.05), dtype)
+    bias = _rand(cout, seed=13)
+    rv = _rand(b, cout, seed=14)
+    res = q(_rand(b, cout, h, w_, seed=15), dtype)
+    ref = (F.conv2d(torch.cat([x0, x1], 1), wt, bias, padding=1) + rv[:, :, None, None]) * 0.5 + res
+    wd = W.pack_conv_split(wt, c0, c0, c1, c1).to(dev, dtype)
+    out = ops.conv(to_nhwc(x0, dtype, dev), wd, bias.to(dev), kh=3, kw=3, pad=1, x2=to_nhwc(x1, dtype, dev),
+                   rowvec=rv.to(dev), residual=to_nhwc(res, dtype, dev), alpha=0.5)
+    assert_close(from_nhwc(out, cout), ref, dtype, what="concat conv")
+    # same vector for every batch (ldrv = 0)
+    out2 = ops.conv(to_nhwc(x0, dtype, dev), wd, bias.to(dev), kh=3, kw=3, pad=1, x2=to_nhwc(x1, dtype, dev),
+                    rowvec=rv[0].to(dev))
+    ref2 = F.conv2d(torch.cat([x0, x1], 1), wt, bias, padding=1) + rv[0][None, :, None, None]
+    assert_close(from_nhwc(out2, cout), ref2, dtype, what="concat conv shared rowvec")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_full_width_level(dev, dtype):
+    """A real SD-1.5 shape: L2 resnet conv (1280 -> 1280 @ 16x16, B=2): K = 11 520."""
+    b, h, w_, c = 2, 16, 16, 1280
+    x = q(_rand(b, c, h, w_, seed=16), dtype)
+    wt = q(_rand(c, c, 3, 3, seed=17, scale=1 / math.sqrt(9 * c)), dtype)
+    ref = F.conv2d(x, wt, None, padding=1)
+    out = ops.conv(to_nhwc(x, dtype, dev), W.pack_conv(wt).to(dev, dtype), kh=3, kw=3, pad=1)
+    assert_close(from_nhwc(out), ref, dtype, what="L2 conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched(dev, dtype):
+    """Scores Q K^T per (batch, head) with interleaved heads, then V^T via swapped operands."""
+    bsz, heads, n, d = 2, 3, 50, 40
+    c = heads * d
+    qk = q(_rand(bsz, n, 2 * c, seed=18), dtype)
+    qd = qk.to(dev, dtype)
+    ld_s = 56
+    s = torch.zeros(bsz, heads, n, ld_s, device=dev, dtype=dtype)
+    ops.gemm_batched(qd[:, :, :c], 2 * c, (n * 2 * c, d), qd[:, :, c:], 2 * c, (n * 2 * c, d), s, ld_s,
+                     (heads * n * ld_s, n * ld_s), n, n, d, bsz, heads)
+    qq = qk[:, :, :c].reshape(bsz, n, heads, d).transpose(1, 2)
+    kk = qk[:, :, c:].reshape(bsz, n, heads, d).transpose(1, 2)
+    ref = qq @ kk.transpose(-1, -2)
+    assert_close(s.float().cpu()[..., :n], ref, dtype, scale=4.0, what="batched QK^T")
+    assert s[..., n:].abs().max().item() == 0
+    # V^T[b] = Wv @ x_b^T
+    x = q(_rand(bsz, n, 64, seed=19), dtype)
+    wv = q(_rand(c, 64, seed=20, scale=0.1), dtype)
+    vt = torch.zeros(bsz, c, ld_s, device=dev, dtype=dtype)
+    ops.gemm_batched(wv.to(dev, dtype), 64, (0, 0), x.to(dev, dtype), 64, (n * 64, 0), vt, ld_s, (c * ld_s, 0), c, n, 64,
+                     bsz, 1)
+    refv = (x @ wv.t()).transpose(1, 2)
+    assert_close(vt.float().cpu()[..., :n], refv, dtype, what="V^T projection")
+
+
+# ------------------------------------------------------------------ attention
+def _ref_attn(qq, kk, vv, heads, causal=False):
+    b, nq, c = qq.shape
+    d = c // heads
+    a = qq.view(b, nq, heads, d).transpose(1, 2)
+    k2 = kk.view(b, -1, heads, d).transpose(1, 2)
+    v2 = vv.view(b, -1, heads, d).transpose(1, 2)
+    s = a @ k2.transpose(-1, -2) * d ** -0.5
+    if causal:
+        s = s + torch.full((nq, k2.shape[2]), float("-inf")).triu_(1)
+    return (torch.softmax(s, -1) @ v2).transpose(1, 2).reshape(b, nq, c)
+
+
+@pytest.mark.parametrize("d,heads,nq,nk,causal", [
+    (40, 8, 200, 200, False), (80, 4, 300, 300, False), (160, 2, 256, 256, False), (64, 3, 77, 77, True),
+    (40, 8, 130, 77, False), (8, 4, 64, 64, False), (16, 2, 33, 200, False), (32, 4, 128, 64, False),
+    (40, 2, 1024, 1024, False)])
+def test_flash_attn(dev, d, heads, nq, nk, causal):
+    dtype = torch.bfloat16
+    bsz, c = 2, heads * d
+    qq = q(_rand(bsz, nq, c, seed=21), dtype)
+    kk = q(_rand(bsz, nk, c, seed=22), dtype)
+    vv = q(_rand(bsz, nk, c, seed=23), dtype)
+    ref = _ref_attn(qq, kk, vv, heads, causal)
+    ldvt = ops.round8(nk) + 8
+    vt = torch.full((bsz, c, ldvt), float("nan"), device=dev, dtype=dtype)   # pad columns must be ignored
+    vt[:, :, :nk] = vv.transpose(1, 2).to(dev, dtype)
+    # q and k live interleaved in one buffer like a fused projection output
+    qkbuf = torch.zeros(bsz, max(nq, nk), 2 * c, device=dev, dtype=dtype)
+    qkbuf[:, :nq, :c] = qq.to(dev, dtype)
+    qkbuf[:, :nk, c:] = kk.to(dev, dtype)
+    out = torch.zeros(bsz, nq, c, device=dev, dtype=dtype)
+    ops.flash_attn(qkbuf[:, :nq, :c], qkbuf[:, :nk, c:], vt, out, heads, d, nq, nk, d ** -0.5, causal)
+    assert_close(out.float().cpu(), ref, dtype, what=f"flash d={d} nq={nq} nk={nk}")
+
+
+def test_flash_attn_rescale_branch(dev):
+    """Force the online-softmax running max to jump at a later KV tile (spiked key)."""
+    dtype = torch.bfloat16
+    bsz, heads, d, n = 1, 1, 40, 256
+    qq = q(_rand(bsz, n, d, seed=24), dtype)
+    kk = q(_rand(bsz, n, d, seed=25), dtype)
+    vv = q(_rand(bsz, n, d, seed=26), dtype)
+    kk[0, 200] = qq[0, 5] * 6.0      # query 5 meets a huge score in the 4th tile
+    kk = q(kk, dtype)
+    ref = _ref_attn(qq, kk, vv, heads)
+    vt = vv.transpose(1, 2).contiguous().to(dev, dtype)
+    out = torch.zeros(bsz, n, d, device=dev, dtype=dtype)
+    ops.flash_attn(qq.to(dev, dtype), kk.to(dev, dtype), vt, out, heads, d, n, n, d ** -0.5)
+    assert_close(out.float().cpu(), ref, dtype, what="flash rescale")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [False, True])
+def test_softmax_rows(dev, dtype, causal):
+    mats, n, ld = 6, 77, 80
+    x = q(_rand(mats, n, ld, seed=27, scale=3.0), dtype)
+    xs = x[..., :n] * 0.3
+    if causal:
+        xs = xs + torch.full((n, n), float("-inf")).triu_(1)
+    ref = torch.softmax(xs, -1)
+    xd = x.to(dev, dtype)
+    ops.softmax_rows(xd, n, 0.3, causal, n)
+    assert_close(xd.float().cpu()[..., :n], ref, dtype, what="softmax")
+    assert xd[..., n:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ norms / elementwise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,w_,c,groups,act", [(2, 16, 16, 320, 32, 1), (2, 8, 8, 64, 8, 0), (1, 64, 64, 128, 32, 1),
+                                                   (3, 5, 7, 40, 5, 0), (2, 8, 8, 2560, 32, 1)])
+def test_groupnorm(dev, dtype, b, h, w_, c, groups, act):
+    x = q(_rand(b, c, h, w_, seed=28) * 2 + 0.5, dtype)
+    g, be = 1 + 0.1 * _rand(c, seed=29), 0.1 * _rand(c, seed=30)
+    ref = F.group_norm(x, groups, g, be, 1e-5)
+    if act:
+        ref = F.silu(ref)
+    out = ops.groupnorm(to_nhwc(x, dtype, dev), g.to(dev), be.to(dev), groups, 1e-5, act)
+    assert_close(from_nhwc(out), ref, dtype, what="groupnorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_concat(dev, dtype):
+    b, h, w_, c0, c1, groups = 2, 8, 8, 64, 32, 8
+    x0, x1 = q(_rand(b, c0, h, w_, seed=31), dtype), q(_rand(b, c1, h, w_, seed=32) * 3, dtype)
+    g, be = 1 + 0.1 * _rand(c0 + c1, seed=33), 0.1 * _rand(c0 + c1, seed=34)
+    ref = F.silu(F.group_norm(torch.cat([x0, x1], 1), groups, g, be, 1e-6))
+    out = ops.groupnorm(to_nhwc(x0, dtype, dev), g.to(dev), be.to(dev), groups, 1e-6, 1, x2=to_nhwc(x1, dtype, dev))
+    assert_close(from_nhwc(out), ref, dtype, what="groupnorm concat")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c", [(300, 320), (77, 768), (5, 1280), (1000, 64)])
+def test_layernorm(dev, dtype, rows, c):
+    x = q(_rand(rows, c, seed=35) * 2 + 1, dtype)
+    g, be = 1 + 0.1 * _rand(c, seed=36), 0.1 * _rand(c, seed=37)
+    ref = F.layer_norm(x, (c,), g, be, 1e-5)
+    out = ops.layernorm(x.to(dev, dtype), g.to(dev), be.to(dev), 1e-5)
+    assert_close(out.float().cpu(), ref, dtype, what="layernorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu_activation(dev, dtype):
+    x = q(_rand(123, 2 * 96, seed=38) * 2, dtype)
+    ref = x[:, :96] * F.gelu(x[:, 96:])
+    assert_close(ops.geglu(x.to(dev, dtype)).float().cpu(), ref, dtype, what="geglu")
+    assert_close(ops.activation(x.to(dev, dtype), ops.ACT_SILU).float().cpu(), F.silu(x), dtype, what="silu")
+    assert_close(ops.activation(x.to(dev, dtype), ops.ACT_QUICK_GELU).float().cpu(), x * torch.sigmoid(1.702 * x), dtype,
+                 what="quick gelu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_scale_cfg_ddim(dev, dtype):
+    tok, pos = q(_rand(50, 64, seed=39), dtype), q(_rand(7, 64, seed=40), dtype)
+    ids = torch.tensor([3, 49, 0, 7, 7, 1, 2, 10, 11, 12, 13, 14, 15, 16])
+    ref = tok[ids] + pos[torch.arange(14) % 7]
+    out = ops.embed_tokens(ids.to(dev), tok.to(dev, dtype), pos.to(dev, dtype), 7)
+    assert_close(out.float().cpu(), ref, dtype, what="embed")
+    x = q(_rand(1000, 8, seed=41), dtype)
+    assert_close(ops.scale(x.to(dev, dtype), 1 / 0.18215).float().cpu(), x / 0.18215, dtype, scale=6.0, what="scale")
+    # cfg + ddim
+    nimg, hw = 2, 300
+    eps = q(_rand(2 * nimg, hw, 8, seed=42), dtype)
+    xx = q(_rand(nimg, hw, 8, seed=43), dtype)
+    xx[..., 4:] = 0
+    x2 = torch.cat([xx, xx], 0)
+    a_t, a_p, gs = 0.3, 0.45, 7.5
+    e = eps[:nimg] + gs * (eps[nimg:] - eps[:nimg])
+    x0 = (xx - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+    ref = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+    xd = x2.to(dev, dtype)
+    ops.cfg_ddim_step(eps.to(dev, dtype), xd, nimg, hw, 4, gs, a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5)
+    got = xd.float().cpu()
+    assert_close(got[:nimg, :, :4], ref[..., :4], dtype, scale=10.0, what="cfg ddim")
+    assert torch.equal(got[:nimg], got[nimg:]) and got[..., 4:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_u8_conversions(dev, dtype):
+    g = torch.Generator().manual_seed(44)
+    img = torch.randint(0, 256, (2, 9, 11, 3), generator=g, dtype=torch.uint8)
+    act = ops.u8_to_act(img.to(dev), dtype)
+    ref = img.float() / 255.0
+    assert_close(act.float().cpu()[..., :3], ref, dtype, what="u8->act")
+    assert act[..., 3:].abs().max().item() == 0
+    x = q(_rand(2, 9, 11, 8, seed=45) * 1.5, dtype)
+    ref8 = ((x[..., :3] / 2 + 0.5).clamp(0, 1).numpy() * 255).round().astype("uint8")
+    got = ops.act_to_u8(x.to(dev, dtype)).cpu().numpy()
+    assert np.abs(got.astype(int) - ref8.astype(int)).max() <= (0 if dtype == torch.float32 else 1)
+
+
+# ------------------------------------------------------------------ Canny (bit exact vs the oracle)
+def _synthetic_image(h, w, seed):
+    from saspa_aug_amd.synthetic import synthetic_image
+    return synthetic_image(h, w, seed)
+
+
+@pytest.mark.parametrize("h,w,seed", [(64, 64, 0), (96, 160, 1), (512, 512, 2), (37, 53, 3), (512, 704, 4)])
+def test_canny_bit_exact(dev, h, w, seed):
+    from oracle import canny as OC
+    img = _synthetic_image(h, w, seed)
+    ref = OC.generate_canny_array(img, 120, 200)
+    got = ops.canny(torch.from_numpy(img)[None].to(dev), 120, 200)[0].cpu().numpy()
+    assert ref.shape == got.shape
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} differing bytes; edge fraction {ref.mean() / 255:.3f}"
+    assert 0.005 < ref.mean() / 255 < 0.5
+
+
+def test_canny_noise_and_flat(dev):
+    from oracle import canny as OC
+    rng = np.random.RandomState(5)
+    noise = rng.randint(0, 256, (2, 80, 96, 3)).astype(np.uint8)
+    flat = np.full((1, 40, 40, 3), 77, np.uint8)
+    for batch in (noise, flat):
+        got = ops.canny(torch.from_numpy(batch).to(dev), 120, 200).cpu().numpy()
+        for i in range(batch.shape[0]):
+            assert np.array_equal(got[i], OC.generate_canny_array(batch[i], 120, 200))

@@ -306,12 +306,9 @@ class UNet(_Net):
         s = ops.groupnorm(s, p["conv_norm_out.g"], p["conv_norm_out.b"], cfg["groups"], 1e-5, SILU)
         return ops.conv(s, p["conv_out.w"], p["conv_out.b"], kh=3, kw=3, pad=1, out=out)
 
-    def forward(self, sample, step, down_residuals=None, mid_residual=None):
-        """Plain UNet forward (tests): residuals are added with an identity 'conv'-free path."""
+    def forward(self, sample, step):
+        """UNet forward without ControlNet residuals."""
         mid, skips = self.encode(sample, step)
-        if down_residuals is not None:
-            skips = [a + b for a, b in zip(skips, down_residuals)]   # test-only host add
-            mid = mid + mid_residual
         return self.decode(mid, skips, step)
 
 

@@ -1,0 +1,185 @@
+"""Drop-in for the diffusers pipeline object the reference builds in `init_pipeline`
+(run_aug/run_aug.py:128-230) and calls at run_aug/run_aug.py:278:
+
+    pipe = StableDiffusionControlNetPipeline.from_pretrained(...).to(DEVICE, torch.float16)
+    pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+    image = pipe(prompt=..., image=<canny PIL>, num_inference_steps=..., generator=...,
+                 guidance_scale=7.5, negative_prompt=..., controlnet_conditioning_scale=0.75).images[0]
+
+Same names, argument meaning and error behaviour (Python exceptions; device problems are
+RuntimeError, which is what the reference's loop catches, run_aug/run_aug.py:493).  The whole
+sampling loop runs in the gfx950 kernels; `generate_batch` is the batched form (B images per
+launch sequence, CFG doubles it) that run_aug and bench.py drive.
+
+Precision: `.to(device, torch.float16)` / `torch.bfloat16` selects the bf16 MFMA path (the
+MI355X counterpart of the reference's fp16 CUDA path; bf16 also avoids the SD-VAE fp16
+overflow); `.to(device, torch.float32)` selects the exact-fp32 MFMA path used for the
+end-to-end parity gate against the CPU oracle."""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import models, ops
+from . import weights as W
+from .config import SD15
+from .scheduler import DDIMScheduler
+from .tokenizer import make_tokenizer
+
+
+class PipelineOutput:
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+
+class StableDiffusionControlNetPipeline:
+    def __init__(self, state_dicts, cfgs=SD15, tokenizer=None, scheduler=None):
+        self._state_dicts = state_dicts
+        self.cfgs = cfgs
+        self.scheduler = scheduler or DDIMScheduler()
+        self.tokenizer = tokenizer or make_tokenizer(vocab=cfgs["text"]["vocab"])
+        self.device = None
+        self.dtype = None
+        self.noise_dtype = None
+        self.unet = self.controlnet = self.vae = self.text_encoder = None
+        self._neg_cache = {}
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def from_synthetic(cls, cfgs=SD15, seed=0):
+        """Architecture-exact random weights (no checkpoint / network available)."""
+        return cls(W.synth_family(cfgs, seed), cfgs)
+
+    @classmethod
+    def from_pretrained(cls, base_dir, controlnet_dir, cfgs=SD15):
+        """Local diffusers-format checkpoints (the layout `from_pretrained` downloads):
+        {base}/unet, {base}/vae, {base}/text_encoder, {base}/tokenizer and the ControlNet dir."""
+        def f(d, *names):
+            for n in names:
+                p = os.path.join(d, n)
+                if os.path.exists(p):
+                    return W.load_safetensors(p)
+            raise FileNotFoundError(f"no safetensors weights in {d}")
+        sds = dict(
+            unet=f(os.path.join(base_dir, "unet"), "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"),
+            vae=f(os.path.join(base_dir, "vae"), "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"),
+            text=f(os.path.join(base_dir, "text_encoder"), "model.safetensors", "model.fp16.safetensors"),
+            controlnet=f(controlnet_dir, "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"),
+        )
+        return cls(sds, cfgs, tokenizer=make_tokenizer(os.path.join(base_dir, "tokenizer"), cfgs["text"]["vocab"]))
+
+    def to(self, device, dtype=None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("saspa_aug_amd pipelines run on an MI355X only (no CPU path); got device %s" % device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible")
+        if dtype in (None, torch.float16, torch.bfloat16):
+            cdt, ndt = torch.bfloat16, torch.float16   # noise is drawn in the reference's pipeline dtype
+        elif dtype == torch.float32:
+            cdt, ndt = torch.float32, torch.float32
+        else:
+            raise TypeError(f"unsupported pipeline dtype {dtype}")
+        self.device, self.dtype, self.noise_dtype = device, cdt, ndt
+        sd, cf = self._state_dicts, self.cfgs
+        self.unet = models.UNet(sd["unet"], cf["unet"], device, cdt)
+        self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt)
+        self.vae = models.VAEDecoder(sd["vae"], cf["vae"], device, cdt)
+        self.text_encoder = models.CLIPText(sd["text"], cf["text"], device, cdt)
+        self._neg_cache = {}
+        return self
+
+    def upcast_vae(self):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
+        return self
+
+    # ---- pieces ------------------------------------------------------------------------
+    def _need_device(self):
+        if self.unet is None:
+            raise RuntimeError("pipeline not placed on a device: call .to('cuda:0', dtype) first")
+
+    def encode_prompts(self, ids):
+        """ids: int array/tensor [n,77] -> [n,77,ctx_dim] device tensor (CLIP text tower)."""
+        self._need_device()
+        ids = torch.as_tensor(np.asarray(ids)).to(self.device)
+        return self.text_encoder.forward(ids)
+
+    def _negative_context(self, neg_ids):
+        key = np.asarray(neg_ids).tobytes()
+        if key not in self._neg_cache:           # constant for a whole run -> encode once
+            self._neg_cache[key] = self.encode_prompts(neg_ids)
+        return self._neg_cache[key]
+
+    def latents_to_device(self, latents):
+        """[B,4,h,w] noise (any float dtype, CPU) -> channels-last [B,h,w,8] in compute dtype."""
+        x = latents.to(torch.float32).permute(0, 2, 3, 1)
+        x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1]))
+        return (x * self.scheduler.init_noise_sigma).to(self.device, self.dtype).contiguous()
+
+    @torch.no_grad()
+    def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps,
+                       guidance_scale=7.5, controlnet_conditioning_scale=0.75, return_latents=False):
+        """prompt_ids [B,77], negative_ids [1,77] or [B,77], control_u8 u8 [B,H,W,3] (numpy or
+        device tensor), latents [B,4,H/8,W/8].  Returns a device u8 tensor [B,H,W,3]."""
+        self._need_device()
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("guidance_scale <= 1 (no CFG) belongs to the SDXL-Turbo branch (SURVEY a9)")
+        dev, dt = self.device, self.dtype
+        ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
+        ctrl = ctrl.to(dev).contiguous()
+        b, hh, ww, _ = ctrl.shape
+        if hh % 8 or ww % 8:
+            raise ValueError("control image sides must be multiples of 8")
+        if tuple(latents.shape) != (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8):
+            raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")
+        pos = self.encode_prompts(prompt_ids)
+        neg = self._negative_context(negative_ids)
+        if neg.shape[0] == 1 and b > 1:
+            neg = neg.expand(b, -1, -1)
+        ctx = torch.cat([neg, pos], 0).contiguous()                       # [2B,77,C]: uncond first
+        cond = ops.u8_to_act(ctrl, dt)
+        cemb = self.controlnet.cond_embedding(cond)
+        cemb2 = torch.cat([cemb, cemb], 0)
+        self.unet.prepare_context(ctx)
+        self.controlnet.prepare_context(ctx)
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        self.unet.prepare_timesteps(ts)
+        self.controlnet.prepare_timesteps(ts)
+        x = self.latents_to_device(latents)
+        x2 = torch.cat([x, x], 0).contiguous()
+        h8, w8 = hh // 8, ww // 8
+        eps = torch.zeros_like(x2)
+        for i, t in enumerate(ts):
+            mid, skips = self.unet.encode(x2, i)
+            skips2, mid2 = self.controlnet.forward(x2, i, cemb2, controlnet_conditioning_scale, skips, mid)
+            self.unet.decode(mid2, skips2, i, out=eps)
+            ops.cfg_ddim_step(eps, x2, b, h8 * w8, self.cfgs["unet"]["out_channels"], guidance_scale,
+                              *self.scheduler.step_coefficients(t))
+        z = ops.scale(x2[:b], 1.0 / self.cfgs["vae"]["scaling_factor"])
+        img = self.vae.decode(z)
+        out = ops.act_to_u8(img)
+        if return_latents:
+            return out, x2[:b], img
+        return out
+
+    # ---- the reference's call form ----------------------------------------------------
+    def __call__(self, prompt=None, image=None, num_inference_steps=50, generator=None, guidance_scale=7.5,
+                 negative_prompt=None, controlnet_conditioning_scale=1.0, **unused):
+        self._need_device()
+        if image is None or prompt is None:
+            raise ValueError("`prompt` and `image` (the control image) are required")
+        ctrl = np.asarray(image.convert("RGB") if isinstance(image, Image.Image) else image, dtype=np.uint8)
+        if ctrl.ndim != 3 or ctrl.shape[2] != 3:
+            raise ValueError("control image must be RGB")
+        hh, ww = ctrl.shape[:2]
+        if generator is not None and generator.device.type != "cpu":
+            raise NotImplementedError("the reference passes the global CPU generator (run_aug/run_aug.py:324)")
+        lat = torch.randn((1, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8), generator=generator,
+                          dtype=self.noise_dtype)
+        ids = self.tokenizer(str(prompt))
+        neg = self.tokenizer(negative_prompt if negative_prompt is not None else "")
+        out = self.generate_batch(ids, neg, ctrl[None], lat, num_inference_steps, guidance_scale,
+                                  controlnet_conditioning_scale)
+        arr = out.cpu().numpy()
+        return PipelineOutput([Image.fromarray(a) for a in arr], [False] * len(arr))

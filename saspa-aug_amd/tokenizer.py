@@ -1,0 +1,94 @@
+"""CLIP tokenizer front-end.
+
+The reference tokenises inside diffusers (`CLIPTokenizer`, 77 tokens, BOS 49406, EOS = PAD =
+49407).  The BPE vocabulary (`vocab.json` + `merges.txt`) ships with the HF
+checkpoint, which is not available offline, so:
+  * `CLIPBPETokenizer(vocab_dir)` implements the published CLIP byte-pair encoding and is
+    used whenever a checkpoint directory provides the two files;
+  * `HashTokenizer` is a deterministic stand-in for synthetic-weight runs: every lower-cased
+    word piece maps to a stable id in [0, vocab-2).  It exists so that the run_aug entrypoint
+    is runnable end to end without a checkpoint; it is NOT a CLIP vocabulary."""
+import json
+import os
+import re
+import zlib
+from functools import lru_cache
+
+import numpy as np
+
+
+class HashTokenizer:
+    def __init__(self, vocab=49408, max_len=77):
+        self.vocab, self.max_len = vocab, max_len
+        self.bos, self.eos = vocab - 2, vocab - 1
+
+    def __call__(self, text):
+        words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", (text or "").lower())
+        ids = [self.bos] + [zlib.crc32(w.encode()) % (self.vocab - 2) for w in words][: self.max_len - 2] + [self.eos]
+        ids += [self.eos] * (self.max_len - len(ids))
+        return np.asarray(ids, np.int64)[None]
+
+
+@lru_cache()
+def _bytes_to_unicode():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
+class CLIPBPETokenizer:
+    def __init__(self, vocab_dir, max_len=77):
+        with open(os.path.join(vocab_dir, "vocab.json"), encoding="utf-8") as f:
+            self.encoder = json.load(f)
+        with open(os.path.join(vocab_dir, "merges.txt"), encoding="utf-8") as f:
+            merges = f.read().strip().split("\n")[1:]
+        self.ranks = {tuple(m.split()): i for i, m in enumerate(merges)}
+        self.byte_enc = _bytes_to_unicode()
+        self.max_len = max_len
+        self.bos, self.eos = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+        self.pat = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[a-z]+|[0-9]|[^\sa-z0-9]+")
+        self.cache = {}
+
+    def _bpe(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        word = tuple(token[:-1]) + (token[-1] + "</w>",)
+        while len(word) > 1:
+            pairs = set(zip(word[:-1], word[1:]))
+            best = min(pairs, key=lambda p: self.ranks.get(p, float("inf")))
+            if best not in self.ranks:
+                break
+            a, b = best
+            out, i = [], 0
+            while i < len(word):
+                if i < len(word) - 1 and word[i] == a and word[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(word[i])
+                    i += 1
+            word = tuple(out)
+        self.cache[token] = word
+        return word
+
+    def __call__(self, text):
+        text = re.sub(r"\s+", " ", (text or "")).strip().lower()
+        ids = []
+        for tok in re.findall(self.pat, text):
+            tok = "".join(self.byte_enc[b] for b in tok.encode("utf-8"))
+            ids += [self.encoder[p] for p in self._bpe(tok)]
+        ids = [self.bos] + ids[: self.max_len - 2] + [self.eos]
+        ids += [self.eos] * (self.max_len - len(ids))
+        return np.asarray(ids, np.int64)[None]
+
+
+def make_tokenizer(vocab_dir=None, vocab=49408):
+    if vocab_dir and os.path.exists(os.path.join(vocab_dir, "vocab.json")):
+        return CLIPBPETokenizer(vocab_dir)
+    return HashTokenizer(vocab)

@@ -1,0 +1,191 @@
+"""GPU parity of the model graphs and of the whole sampling pipeline against the CPU oracle
+(oracle/), on identical seeded weights, noise, token ids and control images.
+
+Tolerances
+  fp32 path : the north-star bar -- atol 1e-3 on the decoded image in [0,1] units
+              (|x/2+0.5| scale, i.e. 2e-3 on the [-1,1] VAE output) and <= 1 u8 level.
+  bf16 path : reported as max-abs / PSNR vs the oracle; bounded loosely (bf16 rounding of
+              every activation compounds through the network)."""
+import numpy as np
+import pytest
+import torch
+
+import saspa_aug_amd  # noqa: F401
+from oracle import pipeline as OP
+from oracle import sd_models as OM
+from saspa_aug_amd import config as CFG
+from saspa_aug_amd import models, ops
+from saspa_aug_amd import weights as W
+from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline
+from saspa_aug_amd.synthetic import synthetic_image
+from tests.util import from_nhwc, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(got, ref):
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+def _limits(dtype):
+    return 2e-4 if dtype == torch.float32 else 6e-2
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfgs = CFG.tiny()
+    return cfgs, W.synth_family(cfgs, seed=3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_clip_text_tiny(dev, tiny, dtype):
+    cfgs, fam = tiny
+    ids = torch.from_numpy(np.random.RandomState(0).randint(0, cfgs["text"]["vocab"], (3, 77)))
+    ref = OM.clip_text_forward(fam["text"], cfgs["text"], ids)
+    net = models.CLIPText(fam["text"], cfgs["text"], dev, dtype)
+    got = net.forward(ids.to(dev)).float().cpu()
+    assert _relerr(got, ref) < _limits(dtype), _relerr(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_clip_text_full_width(dev, dtype):
+    """The real ViT-L/14 text tower shape (123.06 M parameters)."""
+    cfg = CFG.CLIP_L
+    sd = W.synth_state_dict("text", cfg, seed=5)
+    from saspa_aug_amd.synthetic import synthetic_prompt_ids
+    ids = torch.from_numpy(synthetic_prompt_ids(2, seed=2))
+    ref = OM.clip_text_forward(sd, cfg, ids)
+    got = models.CLIPText(sd, cfg, dev, dtype).forward(ids.to(dev)).float().cpu()
+    assert _relerr(got, ref) < _limits(dtype), _relerr(got, ref)
+
+
+def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w, steps=4, step=1):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, 4, h, w, generator=g)
+    ctx = torch.randn(b, 77, cfgs["unet"]["ctx_dim"], generator=g)
+    cond = torch.rand(b, 3, 8 * h, 8 * w, generator=g)
+    sch = OP.DDIM()
+    ts = sch.set_timesteps(steps)
+    t = int(ts[step])
+    down, mid = OM.controlnet_forward(fam["controlnet"], cfgs["controlnet"], x, t, ctx, cond, 0.75)
+    ref = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx, down, mid)
+    ref_plain = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx)
+
+    unet = models.UNet(fam["unet"], cfgs["unet"], dev, dtype)
+    cn = models.ControlNet(fam["controlnet"], cfgs["controlnet"], dev, dtype)
+    ctxd = ctx.to(dev, dtype)
+    for net in (unet, cn):
+        net.prepare_context(ctxd)
+        net.prepare_timesteps(ts)
+    xd = to_nhwc(x, dtype, dev, cpad=8)
+    cemb = cn.cond_embedding(to_nhwc(cond, dtype, dev, cpad=8))
+    # ControlNet alone (no UNet skips fused): residuals vs oracle
+    outs, m = cn.forward(xd, step, cemb, 0.75)
+    errs = [_relerr(from_nhwc(o), r) for o, r in zip(outs, down)] + [_relerr(from_nhwc(m), mid)]
+    # the pipeline's order: UNet encoder -> ControlNet (fused add) -> UNet decoder
+    umid, uskips = unet.encode(xd, step)
+    s2, m2 = cn.forward(xd, step, cemb, 0.75, uskips, umid)
+    got = from_nhwc(unet.decode(m2, s2, step), 4)
+    got_plain = from_nhwc(unet.forward(xd, step), 4)
+    return max(errs), _relerr(got, ref), _relerr(got_plain, ref_plain)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_controlnet_tiny(dev, tiny, dtype):
+    cfgs, fam = tiny
+    e_cn, e_unet, e_plain = _unet_cn_case(cfgs, fam, dev, dtype, 2, 8, 8)
+    lim = _limits(dtype)
+    assert e_cn < lim and e_unet < lim and e_plain < lim, (e_cn, e_unet, e_plain)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_controlnet_nonsquare(dev, tiny, dtype):
+    """Non-square 64x192 image (the reference's images are /64-rounded, rarely square):
+    M is far below one tile at the deep levels (1x3 pixels at the 8x-downsampled level)."""
+    cfgs, fam = tiny
+    e = _unet_cn_case(cfgs, fam, dev, dtype, 1, 8, 24)
+    assert max(e) < _limits(dtype), e
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vae_decode_tiny(dev, tiny, dtype):
+    cfgs, fam = tiny
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(12))
+    ref = OM.vae_decode(fam["vae"], cfgs["vae"], z)
+    vae = models.VAEDecoder(fam["vae"], cfgs["vae"], dev, dtype)
+    got = from_nhwc(vae.decode(to_nhwc(z, dtype, dev, cpad=8)), 3)
+    assert _relerr(got, ref) < _limits(dtype), _relerr(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_controlnet_full_width_step(dev, dtype):
+    """One SD-v1.5 + ControlNet evaluation at full width (859.5 M + 361.3 M parameters),
+    128x128 image (16x16 latents), CFG batch 2 -- every real channel count / head dim."""
+    cfgs = CFG.SD15
+    fam = dict(unet=W.synth_state_dict("unet", cfgs["unet"], 0), controlnet=W.synth_state_dict("controlnet", cfgs["controlnet"], 1))
+    e = _unet_cn_case(cfgs, fam, dev, dtype, 2, 16, 16)
+    assert max(e) < (5e-4 if dtype == torch.float32 else 8e-2), e
+
+
+def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg=1):
+    ids = torch.from_numpy(np.random.RandomState(1).randint(0, cfgs["text"]["vocab"] - 2, (nimg, 77)))
+    neg = torch.from_numpy(np.random.RandomState(2).randint(0, cfgs["text"]["vocab"] - 2, (1, 77)))
+    from oracle.canny import generate_canny_array
+    ctrls = np.stack([generate_canny_array(synthetic_image(hh, ww, 10 + i), 120, 200) for i in range(nimg)])
+    g = torch.manual_seed(1)
+    lat = torch.cat([torch.randn((1, 4, hh // 8, ww // 8), generator=g, dtype=torch.float32) for _ in range(nimg)])
+    refs = [OP.sd_controlnet_pipeline(fam, cfgs, ids[i:i + 1], neg, ctrls[i], lat[i:i + 1], steps, return_latents=True)
+            for i in range(nimg)]
+    pipe = StableDiffusionControlNetPipeline(fam, cfgs).to(dev, dtype)
+    out, x, img = pipe.generate_batch(ids.numpy(), neg.numpy(), ctrls, lat, steps, return_latents=True)
+    ref_u8 = np.concatenate([r[0] for r in refs])
+    ref_img = torch.cat([r[2] for r in refs])
+    got_img = from_nhwc(img, 3)
+    d01 = ((got_img / 2 + 0.5).clamp(0, 1) - (ref_img / 2 + 0.5).clamp(0, 1)).abs().max().item()
+    du8 = np.abs(out.cpu().numpy().astype(int) - ref_u8.astype(int)).max()
+    mse = float(((got_img / 2 + 0.5).clamp(0, 1) - (ref_img / 2 + 0.5).clamp(0, 1)).pow(2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    return d01, int(du8), psnr
+
+
+def test_pipeline_fp32_parity_tiny(dev, tiny):
+    """North-star parity bar, fp32 path: per-pixel atol 1e-3 in [0,1] after 10 DDIM steps."""
+    cfgs, fam = tiny
+    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 64, 10, nimg=2)
+    assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)
+
+
+def test_pipeline_bf16_tiny(dev, tiny):
+    cfgs, fam = tiny
+    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.bfloat16, 64, 64, 10, nimg=2)
+    print(f"bf16 10-step tiny pipeline: max|d|={d01:.4f} (u8 {du8}) PSNR={psnr:.1f} dB")
+    assert psnr > 25.0, (d01, du8, psnr)
+
+
+def test_pipeline_call_form(dev, tiny):
+    """The reference's call form: pipe(prompt, image=PIL, generator=torch.manual_seed(seed), ...)."""
+    from PIL import Image
+    cfgs, fam = tiny
+    pipe = StableDiffusionControlNetPipeline(fam, cfgs).to("cuda:0", torch.float16)
+    ctrl = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    g = torch.manual_seed(1)
+    a = pipe(prompt="an airplane on a runway", image=ctrl, num_inference_steps=3, generator=g, guidance_scale=7.5,
+             negative_prompt="blurry", controlnet_conditioning_scale=0.75).images[0]
+    assert a.size == (96, 64) and a.mode == "RGB"
+    g = torch.manual_seed(1)
+    b = pipe(prompt="an airplane on a runway", image=ctrl, num_inference_steps=3, generator=g, guidance_scale=7.5,
+             negative_prompt="blurry", controlnet_conditioning_scale=0.75).images[0]
+    assert np.array_equal(np.asarray(a), np.asarray(b))          # deterministic given the seed
+    with pytest.raises(RuntimeError):
+        StableDiffusionControlNetPipeline(fam, cfgs).to("cpu", torch.float32)
+
+
+def test_pipeline_fp32_parity_sd15_config1(dev):
+    """BASELINE config 1 at reduced resolution so the CPU oracle finishes in about a minute:
+    full SD-v1.5 + Canny ControlNet + VAE + CLIP-L widths, 1 image 128x128, 1 prompt,
+    10 DDIM steps, fp32 path, atol 1e-3 per pixel."""
+    cfgs = CFG.SD15
+    fam = W.synth_family(cfgs, seed=0)
+    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, 128, 128, 10)
+    print(f"fp32 SD-1.5 config-1 (128x128): max|d|={d01:.2e} u8 diff {du8} PSNR={psnr:.1f}")
+    assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)

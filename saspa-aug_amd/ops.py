@@ -15,6 +15,23 @@ ACT_NONE, ACT_SILU = 0, 1
 ACT_QUICK_GELU = 2  # saspa_activation only
 
 
+# Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)
+# and must return call()'s result.  `flops` is the ALGORITHMIC work of the launch (2*M*N*K
+# for the implicit GEMM, 4*nq*nk*D per head for attention), used for the roofline figures.
+_RECORDER = None
+
+
+def set_recorder(rec):
+    global _RECORDER
+    _RECORDER = rec
+
+
+def _launch(kind, flops, call):
+    if _RECORDER is None:
+        return call()
+    return _RECORDER(kind, flops, call)
+
+
 def _dt(t):
     if t.dtype == torch.bfloat16:
         return _lib.SASPA_BF16
@@ -90,7 +107,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.alpha, p.act = float(alpha), int(act)
     p.out, p.ldo = _ptr(out), _pitch4(out)
     p.nb1 = p.nb2 = 1
-    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)")
+    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"))
     return out
 
 
@@ -123,7 +140,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.out = _ptr(o2)
     p.ldo = o2.stride(0) if m > 1 else max(n, o2.stride(0))
     p.nb1 = p.nb2 = 1
-    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)")
+    _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"))
     if x.dim() != 2 and out.dim() == 2:
         return out.reshape(*x.shape[:-1], out.shape[-1])
     return out
@@ -150,7 +167,8 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.sa1, p.sa2 = sa
     p.sw1, p.sw2 = sw
     p.so1, p.so2 = so
-    _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)")
+    _launch("gemm", 2.0 * m * n * k * nb1 * nb2,
+            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"))
     return out
 
 
@@ -168,7 +186,8 @@ def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False):
     p.o, p.ldo, p.sob = _ptr(out), out.stride(1), out.stride(0)
     p.batch, p.heads, p.D, p.nq, p.nk = q.shape[0], heads, d, nq, nk
     p.scale, p.causal = float(scale), int(causal)
-    _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16")
+    _launch("flash_attn", 4.0 * q.shape[0] * heads * nq * nk * d,
+            lambda: _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16"))
     return out
 
 

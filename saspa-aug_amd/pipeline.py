@@ -102,8 +102,9 @@ class StableDiffusionControlNetPipeline:
     def encode_prompts(self, ids):
         """ids: int array/tensor [n,77] -> [n,77,ctx_dim] device tensor (CLIP text tower)."""
         self._need_device()
-        ids = torch.as_tensor(np.asarray(ids)).to(self.device)
-        return self.text_encoder.forward(ids)
+        if not torch.is_tensor(ids):
+            ids = torch.as_tensor(np.asarray(ids))
+        return self.text_encoder.forward(ids.to(self.device))
 
     def _negative_context(self, neg_ids):
         key = np.asarray(neg_ids).tobytes()
@@ -119,9 +120,12 @@ class StableDiffusionControlNetPipeline:
 
     @torch.no_grad()
     def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps,
-                       guidance_scale=7.5, controlnet_conditioning_scale=0.75, return_latents=False):
+                       guidance_scale=7.5, controlnet_conditioning_scale=0.75, return_latents=False,
+                       latents_on_device=False):
         """prompt_ids [B,77], negative_ids [1,77] or [B,77], control_u8 u8 [B,H,W,3] (numpy or
-        device tensor), latents [B,4,H/8,W/8].  Returns a device u8 tensor [B,H,W,3]."""
+        device tensor), latents [B,4,H/8,W/8] noise (or, with latents_on_device, the
+        channels-last [B,H/8,W/8,8] device tensor from `latents_to_device`).
+        Returns a device u8 tensor [B,H,W,3]."""
         self._need_device()
         if guidance_scale <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) belongs to the SDXL-Turbo branch (SURVEY a9)")
@@ -131,7 +135,8 @@ class StableDiffusionControlNetPipeline:
         b, hh, ww, _ = ctrl.shape
         if hh % 8 or ww % 8:
             raise ValueError("control image sides must be multiples of 8")
-        if tuple(latents.shape) != (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8):
+        want = (b, hh // 8, ww // 8, 8) if latents_on_device else (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
+        if tuple(latents.shape) != want:
             raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")
         pos = self.encode_prompts(prompt_ids)
         neg = self._negative_context(negative_ids)
@@ -146,7 +151,7 @@ class StableDiffusionControlNetPipeline:
         ts = self.scheduler.set_timesteps(num_inference_steps)
         self.unet.prepare_timesteps(ts)
         self.controlnet.prepare_timesteps(ts)
-        x = self.latents_to_device(latents)
+        x = latents if latents_on_device else self.latents_to_device(latents)
         x2 = torch.cat([x, x], 0).contiguous()
         h8, w8 = hh // 8, ww // 8
         eps = torch.zeros_like(x2)

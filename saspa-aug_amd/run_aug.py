@@ -1,0 +1,402 @@
+"""SaSPA augmentation generation -- the host side of the hot path, mirroring the reference's
+`run_aug/run_aug.py` (constants :47-72, init_pipeline :128-230, pass_thorugh_pipe :233-279,
+main :282-504, config/output-tree block :507-733) behind the same switches
+(BASE_MODEL / CONTROLNET / NUM_PER_IMAGE / SEED / PROMPT_TYPE ...) and the same output tree /
+file names / JSON, so `fgvc/train.py` consumes the results unchanged.
+
+What is different by design (MI355X-first; results per work item are unchanged):
+  * the reference generates one variant per `pipe()` call; here a cheap host-only PLANNING
+    pass replays the reference's host RNG (numpy / random / the CPU noise generator, in the
+    reference's exact order) into a manifest of work items, which are bucketed by image size,
+    batched (B images = 2B CFG samples per launch sequence) and sharded across ranks;
+  * each item's initial noise is the slice of the single sequential CPU noise stream the
+    reference would have drawn for it (offset = sum of the preceding latent sizes), so
+    batching and sharding do not change any image;
+  * Canny runs once per source image on the GPU (the reference recomputes it per variant);
+  * PNG encoding is asynchronous (thread pool) so it does not serialise the GPU;
+  * one process per GPU (`torchrun`), no model parallelism; the only collective is one gather
+    of the per-item status vector to rank 0, which then writes the JSON manifest."""
+import logging
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import dataset_utils, utils
+from .prompts_engineering import ARTISTIC_PROMPTS, IMAGE_VARIATIONS_PROMPTS
+
+NEGATIVE_PROMPT = ("over-exposure, under-exposure, saturated, duplicate, out of frame, lowres, cropped, worst quality, "
+                   "low quality, jpeg artifacts, morbid, mutilated, out of frame, ugly, bad anatomy, bad proportions, "
+                   "deformed, blurry, duplicate")                       # run_aug/run_aug.py:47
+MAX_FILENAME_LENGTH = 40
+MAX_PROMPT_LENGTH = 150
+
+BASE_MODEL_DICT = {
+    "sd_v1.5": "runwayml/stable-diffusion-v1-5",
+    "sd_v2.1": "stabilityai/stable-diffusion-2-1-base",
+    "sd_xl": ["stabilityai/stable-diffusion-xl-base-1.0", "stabilityai/stable-diffusion-xl-refiner-1.0"],
+    "sd_xl-turbo": "stabilityai/sdxl-turbo",
+    "blip_diffusion": "Salesforce/blipdiffusion",
+    "blip_diffusion-controlnet": "Salesforce/blipdiffusion-controlnet",
+    "ip2p": "timbrooks/instruct-pix2pix",
+}
+CONTROLNET_DICT_SD = {"canny": "lllyasviel/control_v11p_sd15_canny", "hed": "lllyasviel/sd-controlnet-hed"}
+CONTROLNET_DICT_SD_XL = {"canny": "diffusers/controlnet-canny-sdxl-1.0"}
+
+
+@dataclass
+class Settings:
+    """The module-level constants of the reference's `__main__` block (run_aug/run_aug.py:513-556)."""
+    DEBUG: int = 0
+    SPECIFIC_FILE_STRs: list = None
+    DEVICE: str = "cuda:0"
+    version: str = "v1"
+    DATASET: str = "planes"
+    BASE_MODEL: str = "sd_v1.5"
+    CONTROLNET: str = "canny"
+    SDEDIT: int = 0
+    NUM_PER_IMAGE: int = 2
+    SEED: int = 1
+    PROMPT_TYPE: str = "gpt-meta_class"
+    PROMPT_WITH_SUB_CLASS: bool = True
+    USE_ARTISTIC_PROMPTS: bool = True
+    ARTISTIC_PROMPTS_PROB: float = 0.5
+    USE_CAMERA_VARIATIONS_PROMPTS: bool = False
+    CAMERA_VAIRATIONS_PROB: float = 0.5
+    RESOLUTION: int = 512
+    GUIDANCE_SCALE: float = 7.5
+    NUM_INFERENCE_STEPS: int = 30
+    SDEDIT_STRENGTH: float = 0.85
+    LOW_THRESHOLD_CANNY: int = 120
+    HIGH_THRESHOLD_CANNY: int = 200
+    CONTROLNET_CONDITIONING_SCALE: float = 0.75
+    SEMANTIC_FILTERING: int = 1
+    MODEL_CONFIDENCE_BASED_FILTERING: int = 1
+    # additions of this build
+    BATCH_SIZE: int = 8
+    PRECISION: str = "bf16"            # "bf16" (production) | "fp32" (parity mode)
+    WEIGHTS_DIR: str = None            # local diffusers-format checkpoints; None -> synthetic weights
+    PROMPTS_FILE: str = None
+    DATASET_KWARGS: dict = field(default_factory=dict)
+
+
+@dataclass
+class WorkItem:
+    order: int            # position in the reference's loop order
+    index: int            # source image index
+    source_path: str
+    image_stem: str
+    i: int                # variant number
+    prompt: str
+    output_path: str
+    height: int
+    width: int
+    noise_offset: int = -1   # element offset into the sequential fp16/fp32 CPU noise stream
+    skip: bool = False
+    status: int = 0       # 0 skipped (exists), 1 generated, -1 failed
+
+
+# ------------------------------------------------------------------------------------------
+# configuration -> paths (run_aug/run_aug.py:668-692)
+# ------------------------------------------------------------------------------------------
+def prompt_str_for(s: Settings):
+    p = s.PROMPT_TYPE
+    if s.PROMPT_WITH_SUB_CLASS:
+        p += "_prompt_w_sub_class"
+    if s.USE_ARTISTIC_PROMPTS:
+        p += f"_artistic_prompts_p_{s.ARTISTIC_PROMPTS_PROB}"
+    if s.USE_CAMERA_VARIATIONS_PROMPTS:
+        p += f"_camera_variations_p_{s.CAMERA_VAIRATIONS_PROB}"
+    if "blip_diffusion" in s.BASE_MODEL:
+        p += "_style_img_from_diff_img"
+    return p
+
+
+def output_folder_for(s: Settings, root_path):
+    base_model_folder = f"regular/{s.BASE_MODEL}"
+    if s.SDEDIT:
+        base_model_folder += f"-SDEdit_strength_{s.SDEDIT_STRENGTH}"
+    if s.CONTROLNET:
+        base_model_folder = base_model_folder.replace("regular/", "controlnet/")
+    return f"{root_path}/aug_data/{base_model_folder}/{s.CONTROLNET}/{prompt_str_for(s)}_seed_{s.SEED}/images"
+
+
+def read_prompts(prompts_file):
+    with open(prompts_file, "r") as f:
+        prompts = [p.strip()[:MAX_PROMPT_LENGTH] for p in f.readlines()]
+    return prompts
+
+
+# ------------------------------------------------------------------------------------------
+# pipeline construction / call (run_aug/run_aug.py:128-279)
+# ------------------------------------------------------------------------------------------
+def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="ddim", weights_dir=None, cfgs=None,
+                  state_dicts=None):
+    """(base_model, controlnet, SDEdit) -> pipeline object.  Implemented: sd_v1.5 + canny (the
+    SaSPA configuration for planes and the BASELINE metric).  `use_compile` is accepted and
+    ignored: the reference's torch.compile(reduce-overhead) has no counterpart, the kernels are
+    launched directly."""
+    from .config import SD15
+    from .pipeline import StableDiffusionControlNetPipeline
+    from .scheduler import DDIMScheduler
+    assert base_model in BASE_MODEL_DICT.keys()
+    assert controlnet in CONTROLNET_DICT_SD.keys() or controlnet in CONTROLNET_DICT_SD_XL.keys() or controlnet is None
+    assert sampler in ["ddim", "unipcmultistep"]
+    if base_model != "sd_v1.5" or controlnet != "canny" or SDEdit:
+        raise NotImplementedError(
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): only sd_v1.5 + canny ControlNet is built so far; "
+            "BLIP-Diffusion / SDXL-Turbo are SURVEY 8(a) rows a8 / a9, SDEdit / HED / ip2p are baseline branches")
+    if sampler != "ddim":
+        raise NotImplementedError("UniPC sampler (SURVEY 8(f) f4)")
+    cfgs = cfgs or SD15
+    if state_dicts is not None:
+        pipe = StableDiffusionControlNetPipeline(state_dicts, cfgs)
+    elif weights_dir:
+        pipe = StableDiffusionControlNetPipeline.from_pretrained(
+            os.path.join(weights_dir, BASE_MODEL_DICT[base_model]), os.path.join(weights_dir, CONTROLNET_DICT_SD[controlnet]), cfgs)
+    else:
+        logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
+        pipe = StableDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0)
+    pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+    return pipe
+
+
+def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strength, num_inference_steps, generator,
+                      guidance_scale, control_cond_scale, negative_prompt=NEGATIVE_PROMPT, control_image=None,
+                      blip_src_category=None, blip_target_category=None):
+    """Single-variant call form of the reference (name kept, typo included)."""
+    pipe_args = {"prompt": str(prompt), "num_inference_steps": num_inference_steps, "generator": generator,
+                 "guidance_scale": guidance_scale, "negative_prompt": negative_prompt}
+    if "blip_diffusion" in base_model or "ip2p" in base_model or SDEdit:
+        raise NotImplementedError("only the sd_v1.5 + ControlNet call form is built")
+    if control_image is not None:
+        pipe_args["image"] = control_image
+        pipe_args["controlnet_conditioning_scale"] = control_cond_scale
+    output = pipe(**pipe_args)
+    return output.images[0]
+
+
+# ------------------------------------------------------------------------------------------
+# planning pass: replay of the reference's host RNG (run_aug/run_aug.py:357-434)
+# ------------------------------------------------------------------------------------------
+def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image_classes_dict):
+    """Artistic / camera suffixes and sub-class injection, consuming the python / numpy RNG
+    streams exactly like run_aug/run_aug.py:391-427."""
+    if s.USE_ARTISTIC_PROMPTS and ((i % 2 == 0 and s.ARTISTIC_PROMPTS_PROB == 0.5) or
+                                   (random.random() < s.ARTISTIC_PROMPTS_PROB and s.ARTISTIC_PROMPTS_PROB != 0.5)):
+        prompt = f"{prompt}, {np.random.choice(ARTISTIC_PROMPTS)}"
+    elif s.USE_CAMERA_VARIATIONS_PROMPTS and random.random() < s.CAMERA_VAIRATIONS_PROB:
+        prompt = f"{prompt}, {np.random.choice(IMAGE_VARIATIONS_PROMPTS)} photo"
+    if s.PROMPT_WITH_SUB_CLASS:
+        if s.DATASET in ["planes", "planes_biased", "synthetic"]:
+            prompt = prompt.replace("airplane", f"{image_classes_dict[image_stem]} airplane")
+        elif s.DATASET == "cars":
+            prompt = prompt.replace("car", f"{image_classes_dict[image_stem]} car")
+        else:
+            raise NotImplementedError(s.DATASET)
+    return prompt
+
+
+def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None):
+    """Returns the work items in the reference's loop order.  Must be called right after
+    utils.set_seed(SEED) (and dataset construction), like the reference's loop."""
+    if image_size_fn is None:
+        def image_size_fn(path):
+            with Image.open(path) as im:
+                w, h = im.size
+            th, tw, _ = utils.resize_target_size(h, w, s.RESOLUTION)
+            return th, tw
+    if s.DEBUG:
+        if s.SPECIFIC_FILE_STRs:
+            original_images_paths = [p for p in original_images_paths if any(x in p for x in s.SPECIFIC_FILE_STRs)]
+        else:
+            original_images_paths = original_images_paths[:4]
+    prompts = [p[:-1] if p and p[-1] == "." else p for p in prompts]        # :380 (idempotent)
+    items = []
+    noise_cursor = 0
+    for index, source_image_path in enumerate(original_images_paths):
+        image_stem = Path(source_image_path).stem
+        th, tw = image_size_fn(source_image_path)
+        sampled = np.random.choice(prompts, s.NUM_PER_IMAGE)                 # :382
+        for i, prompt in enumerate(sampled):
+            prompt = decorate_prompt(s, str(prompt), i, image_stem, source_image_path, image_classes_dict)
+            output_path = Path(output_folder) / f"{image_stem[:MAX_FILENAME_LENGTH]}_prompt_{prompt.replace('/', '-')}_{i}.png"
+            it = WorkItem(len(items), index, source_image_path, image_stem, i, prompt, str(output_path), th, tw)
+            if output_path.exists():
+                it.skip = True               # :430-432 -- skipped BEFORE the noise draw
+            else:
+                it.noise_offset = noise_cursor
+                noise_cursor += 4 * (th // 8) * (tw // 8)
+            items.append(it)
+    return items
+
+
+def shard_items(items, world):
+    """Contiguous blocks balanced by sum(H*W) of the items that will actually run."""
+    live = [it for it in items if not it.skip]
+    total = sum(it.height * it.width for it in live)
+    shards = [[] for _ in range(world)]
+    acc, r = 0, 0
+    for it in live:
+        if r < world - 1 and acc >= (r + 1) * total / world:
+            r += 1
+        shards[r].append(it)
+        acc += it.height * it.width
+    return shards
+
+
+def noise_for_items(items_all, mine, seed, dtype):
+    """Replays the single sequential CPU noise stream (generator = torch.manual_seed(SEED),
+    run_aug/run_aug.py:324) in work-item order and returns {order: [1,4,h,w]} for `mine`."""
+    want = {it.order for it in mine}
+    last = max(want) if want else -1
+    g = torch.manual_seed(seed)
+    out = {}
+    for it in items_all:
+        if it.skip:
+            continue
+        if it.order > last:
+            break
+        n = torch.randn((1, 4, it.height // 8, it.width // 8), generator=g, dtype=dtype)
+        if it.order in want:
+            out[it.order] = n
+    return out
+
+
+def make_batches(mine, batch_size):
+    buckets = {}
+    for it in mine:
+        buckets.setdefault((it.height, it.width), []).append(it)
+    batches = []
+    for key in sorted(buckets):
+        b = buckets[key]
+        batches += [b[j:j + batch_size] for j in range(0, len(b), batch_size)]
+    return batches
+
+
+# ------------------------------------------------------------------------------------------
+# generation of one batch of work items on the GPU
+# ------------------------------------------------------------------------------------------
+def hip_batch_generator(pipe, s: Settings):
+    """Returns fn(batch_items, noises[list of [1,4,h,w]], source_u8 [B,H,W,3]) -> (images u8
+    [B,H,W,3] numpy, control u8 [B,H,W,3] numpy), running Canny + sampling on the device."""
+    from . import ops
+    tok = pipe.tokenizer
+    neg_ids = tok(NEGATIVE_PROMPT)
+
+    def run(batch, noises, sources):
+        src = torch.from_numpy(np.ascontiguousarray(sources)).to(pipe.device)
+        ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)
+        ids = np.concatenate([tok(it.prompt) for it in batch])
+        lat = torch.cat(noises)
+        out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
+                                  s.CONTROLNET_CONDITIONING_SCALE)
+        return out.cpu().numpy(), ctrl.cpu().numpy()
+    return run
+
+
+def load_source(path, resolution):
+    """diffusers.utils.load_image + utils.resize_image (run_aug/run_aug.py:372-374)."""
+    from PIL import ImageOps
+    img = ImageOps.exif_transpose(Image.open(path)).convert("RGB")
+    return utils.resize_image(np.array(img), resolution)
+
+
+def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None):
+    """The generation loop.  `batch_generator` is injectable for host-logic tests; the default
+    builds the HIP pipeline (fails loudly without an MI355X)."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    utils.set_seed(s.SEED)
+    if ds_utils is None:
+        ds_utils = dataset_utils.DS_UTILS_DICT[s.DATASET](**s.DATASET_KWARGS)
+    prompts_file = s.PROMPTS_FILE or str(Path("prompts_engineering/gpt_prompts") / f"{'planes' if s.DATASET != 'cars' else 'cars'}-100-gpt_v1.txt")
+    output_folder = output_folder_for(s, ds_utils.root_path)
+    if rank == 0:
+        Path(output_folder).mkdir(parents=True, exist_ok=True)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        utils.init_logging(str(Path(output_folder).parent))
+    image_classes_dict = ds_utils.get_image_stem_to_class_str_dict()
+    prompts = read_prompts(prompts_file)
+    logging.info(f"Read {len(prompts)} prompts from {prompts_file}")
+    aug_json_path = utils.get_aug_json_path(output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
+                                            model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING)
+    logging.info(f"Augmented json path will be at: \n{aug_json_path}")
+
+    items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict)
+    mine = shard_items(items, world)[rank]
+    logging.info(f"rank {rank}/{world}: {len(mine)} of {len(items)} work items ({sum(i.skip for i in items)} already exist)")
+
+    if batch_generator is None:
+        if pipe is None:
+            pipe = init_pipeline(s.BASE_MODEL, s.CONTROLNET, s.SDEDIT, weights_dir=s.WEIGHTS_DIR)
+            pipe = pipe.to(s.DEVICE, torch.float32 if s.PRECISION == "fp32" else torch.float16)
+        batch_generator = hip_batch_generator(pipe, s)
+        noise_dtype = pipe.noise_dtype
+    else:
+        noise_dtype = torch.float32 if s.PRECISION == "fp32" else torch.float16
+    noises = noise_for_items(items, mine, s.SEED, noise_dtype)        # generator = torch.manual_seed(SEED) (:324)
+
+    first_variant = {}
+    for it in items:
+        first_variant.setdefault(it.index, it.order)
+    num_errors = 0
+    pool = ThreadPoolExecutor(max_workers=4)
+    futures = []
+    for batch in make_batches(mine, s.BATCH_SIZE):
+        try:
+            sources = np.stack([load_source(it.source_path, s.RESOLUTION) for it in batch])
+            images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources)
+        except KeyboardInterrupt:
+            raise
+        except RuntimeError as e:            # the reference treats RuntimeError as OOM (:493-500); isolate per batch
+            logging.exception(e)
+            num_errors += 1
+            for it in batch:
+                it.status = -1
+            if num_errors > 20:
+                logging.info("Too many errors, stopping generation on this rank")
+                break
+            continue
+        for k, it in enumerate(batch):
+            stem40 = it.image_stem[:MAX_FILENAME_LENGTH]
+            if first_variant[it.index] == it.order:
+                futures.append(pool.submit(Image.fromarray(sources[k]).save, os.path.join(output_folder, f"{stem40}_source.png")))
+                if it.index < 10:
+                    futures.append(pool.submit(Image.fromarray(controls[k]).save, f"{output_folder}/{stem40}_control.png"))
+            futures.append(pool.submit(Image.fromarray(images[k]).save, it.output_path))
+            it.status = 1
+    for f in futures:
+        f.result()
+    pool.shutdown()
+
+    # ---- the one collective: per-item status vector -> rank 0 ----
+    status = torch.zeros(len(items), dtype=torch.int32)
+    for it in mine:
+        status[it.order] = it.status
+    if dist is not None:
+        dev = torch.device(s.DEVICE) if dist.get_backend() == "nccl" else torch.device("cpu")
+        st = status.to(dev)
+        gathered = [torch.empty_like(st) for _ in range(world)] if rank == 0 else None
+        dist.gather(st, gathered, dst=0)
+        if rank == 0:
+            status = torch.stack([g.cpu() for g in gathered]).sum(0).to(torch.int32)   # shards are disjoint
+    json_path = None
+    if rank == 0:
+        logging.info(f"Done Generating: {(status == 1).sum().item()} generated, {(status == -1).sum().item()} failed, "
+                     f"{sum(i.skip for i in items)} skipped (already existed)")
+        n_files = len(list(Path(output_folder).glob("*.*")))
+        json_path = utils.create_json_of_image_name_to_augmented_images_paths(
+            ds_utils, output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
+            model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING, init_log=False,
+            original_images_paths=ds_utils.original_images_paths, min_files=min(10, max(1, n_files)))
+    if dist is not None:
+        dist.barrier()
+    return dict(items=items, status=status, json_path=json_path, output_folder=output_folder)

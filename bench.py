@@ -47,18 +47,18 @@ class Recorder:
     def __init__(self):
         self.items = []
 
-    def __call__(self, kind, flops, call):
+    def __call__(self, kind, flops, call, meta=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = call()
         e1.record()
-        self.items.append((kind, flops, e0, e1))
+        self.items.append((kind, flops, e0, e1, meta))
         return r
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1 in self.items:
+        for kind, flops, e0, e1, _ in self.items:
             d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops

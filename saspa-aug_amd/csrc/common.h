@@ -32,9 +32,12 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
   f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
-  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  // one v_cvt_pk_bf16_f32 (RNE, NaN-preserving); the scalar-cast form costs 2 cvt + an sdwa or
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ uint4 pack8(const float* f) {

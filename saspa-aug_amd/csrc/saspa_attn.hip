@@ -19,8 +19,10 @@
 
 namespace {
 
-template <int KS, int NB>
+template <int KS, int NB, bool ONES>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
+  // ONES: D < 32*NB, so V^T row D is a spare MFMA row; it is filled with ones and the PV
+  // MFMA then accumulates the softmax denominator there (no VALU row-sum in the loop).
   constexpr int KSLOTS = (2 * KS) | 1;       // 16-byte slots per K row (odd)
   constexpr int KCH = 2 * KS;                // chunks per K row that are written
   constexpr int DV = NB * 32;
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
 
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const u32x4 ones4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // bf16 1.0 x8
 
   // ---- Q fragments (B operand), resident for the whole kernel ----
   u32x4 qf[KS];
@@ -57,46 +60,60 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
   }
 
-  f32x16 acc_o[NB];
+  // ---- staging bookkeeping (loop invariant per thread) ----
+  int k_key[NCH_K], k_ch[NCH_K];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float c = p.scale * 1.4426950408889634f;
+  for (int i = 0; i < NCH_K; ++i) {
+    const int q = tid + 256 * i;
+    k_key[i] = q / KCH;
+    k_ch[i] = q - k_key[i] * KCH;
+  }
+  u32x4 kreg[NCH_K], vreg[NCH_V];
 
-  const int ntiles = (p.nk + 63) / 64;
-  for (int t = 0; t < ntiles; ++t) {
-    const int key0 = t * 64;
-    // ---- stage K tile [64][D] and V^T tile [D][64] ----
-    __syncthreads();  // previous tile fully consumed
+  auto load_tile = [&](int key0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NCH_K; ++i) {
       const int q = tid + 256 * i;
-      if (q < 64 * KCH) {
-        const int key = q / KCH, ch = q - key * KCH;
-        u32x4 v = zero4;
-        if (ch < D8 && key0 + key < p.nk) v = *reinterpret_cast<const u32x4*>(Kp + (long long)(key0 + key) * p.ldk + ch * 8);
-        *reinterpret_cast<u32x4*>(ksm + (key * KSLOTS + ch) * 16) = v;
+      u32x4 v = zero4;
+      if (q < 64 * KCH && k_ch[i] < D8 && key0 + k_key[i] < p.nk)
+        v = *reinterpret_cast<const u32x4*>(Kp + (long long)(key0 + k_key[i]) * p.ldk + k_ch[i] * 8);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      const int q = tid + 256 * i;
+      const int d = q >> 3, kk = key0 + (q & 7) * 8;
+      u32x4 v = zero4;
+      if (q < DV * 8) {
+        if (d < D) {
+          if (kk < p.nk) v = *reinterpret_cast<const u32x4*>(VT + (long long)d * p.ldvt + kk);
+        } else if (ONES && d == D) {
+          v = ones4;
+        }
       }
+      vreg[i] = v;
+    }
+  };
+  auto store_tile = [&](int key0) __attribute__((always_inline)) {
+    const bool tail = key0 + 64 > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i) {
+      const int q = tid + 256 * i;
+      if (q < 64 * KCH) *reinterpret_cast<u32x4*>(ksm + (k_key[i] * KSLOTS + k_ch[i]) * 16) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
       const int q = tid + 256 * i;
       if (q < DV * 8) {
         const int d = q >> 3, kc = q & 7;
-        const int kk = key0 + kc * 8;
-        u32x4 v = zero4;
-        if (d < D && kk < p.nk) {
-          v = *reinterpret_cast<const u32x4*>(VT + (long long)d * p.ldvt + kk);
-          const int nvalid = p.nk - kk;  // >= 1
-          if (nvalid < 8) {
-            // zero the keys >= nk (pad columns of vt are not initialised by the producer)
+        u32x4 v = vreg[i];
+        if (tail && d < D) {
+          // zero the keys >= nk (pad columns of vt are not initialised by the producer)
+          const int nvalid = p.nk - (key0 + kc * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (2 * e >= nvalid) v[e] = 0;
-              else if (2 * e + 1 >= nvalid) v[e] &= 0x0000ffffu;
-            }
+          for (int e = 0; e < 4; ++e) {
+            const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
+            v[e] &= keep;
           }
         }
         u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
@@ -104,53 +121,75 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
         dst[1] = u32x2{v.z, v.w};
       }
     }
+  };
+
+  f32x16 acc_o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
+  const float c = p.scale * 1.4426950408889634f;   // scores are kept raw; exp2(s*c - m) folds the scale
+  float m_run = -1e30f;                             // running max, already multiplied by c
+  float l_run = 0.f;                                // VALU row-sum (only when !ONES)
+
+  const int ntiles = (p.nk + 63) / 64;
+  load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * 64;
+    __syncthreads();            // previous tile fully consumed
+    store_tile(key0);
     __syncthreads();
+    if (t + 1 < ntiles) load_tile(key0 + 64);   // in flight during the MFMA / softmax block below
 
     // ---- S^T = K Q^T for two 32-key blocks ----
     f32x16 acc_s[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc_s[kb][i] = 0.f;
-#pragma unroll
       for (int s = 0; s < KS; ++s) {
         const u32x4 kf = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
-        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                            __builtin_bit_cast(bf16x8, qf[s]), acc_s[kb], 0, 0, 0);
+        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]),
+                                                            s == 0 ? zero16 : acc_s[kb], 0, 0, 0);   // C = inline 0
       }
     }
-    // ---- mask + online softmax (query on the lane) ----
-    float mx = -INFINITY;
+    // ---- masks only on the tiles that need them (wave-uniform) ----
+    if (key0 + 64 > p.nk || p.causal) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        float sc = acc_s[kb][i] * c;
-        if (key >= p.nk || (p.causal && key > qi)) sc = -INFINITY;
-        acc_s[kb][i] = sc;
-        mx = fmaxf(mx, sc);
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= p.nk || (p.causal && key > qi)) acc_s[kb][i] = -INFINITY;
+        }
+    }
+    // ---- online softmax, query on the lane ----
+    float mx = fmaxf(acc_s[0][0], acc_s[1][0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(acc_s[0][i], acc_s[1][i]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, mx * c);
+    if (__any(m_new > m_run)) {   // some query's max moved: rescale everything at the old max once
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      if (!ONES) l_run *= alpha;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(acc_s[kb][i] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][i], c, -m_run));
         acc_s[kb][i] = pv;
-        psum += pv;
+        if (!ONES) psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
+    if (!ONES) l_run += psum;
 
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T  (row D of V^T is ones when ONES: accumulates the denominator) ----
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kb = ks >> 1, half = ks & 1;
@@ -173,7 +212,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   }
 
   // ---- normalise and store: lane holds O[qi][d], d = 32*nb + 8*g + 4*h + (0..3) ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if (ONES) {
+    // the denominator sits in accumulator row D: block D/32, register 4*((D%32)/8), half h = 0
+    float lsel = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * nb + 8 * g == D) lsel = acc_o[nb][4 * g];
+    l_tot = __shfl(lsel, r, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   if (qi < p.nq) {
 #pragma unroll
@@ -193,7 +244,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
-  hipLaunchKernelGGL((flash_attn_kernel<KS, NB>), grid, dim3(256), 0, s, p);
+  if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false>), grid, dim3(256), 0, s, p);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

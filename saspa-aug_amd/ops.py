@@ -26,10 +26,10 @@ def set_recorder(rec):
     _RECORDER = rec
 
 
-def _launch(kind, flops, call):
+def _launch(kind, flops, call, meta=None):
     if _RECORDER is None:
         return call()
-    return _RECORDER(kind, flops, call)
+    return _RECORDER(kind, flops, call, meta)
 
 
 def _dt(t):
@@ -107,7 +107,8 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.alpha, p.act = float(alpha), int(act)
     p.out, p.ldo = _ptr(out), _pitch4(out)
     p.nb1 = p.nb2 = 1
-    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"))
+    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
+            (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
     return out
 
 
@@ -140,7 +141,8 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.out = _ptr(o2)
     p.ldo = o2.stride(0) if m > 1 else max(n, o2.stride(0))
     p.nb1 = p.nb2 = 1
-    _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"))
+    _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),
+            (m, n, k, 0, 1, 0, False))
     if x.dim() != 2 and out.dim() == 2:
         return out.reshape(*x.shape[:-1], out.shape[-1])
     return out
@@ -168,7 +170,7 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.sw1, p.sw2 = sw
     p.so1, p.so2 = so
     _launch("gemm", 2.0 * m * n * k * nb1 * nb2,
-            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"))
+            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"), (m, n, k, -nb1 * nb2, 1, 0, False))
     return out
 
 
@@ -187,7 +189,8 @@ def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False):
     p.batch, p.heads, p.D, p.nq, p.nk = q.shape[0], heads, d, nq, nk
     p.scale, p.causal = float(scale), int(causal)
     _launch("flash_attn", 4.0 * q.shape[0] * heads * nq * nk * d,
-            lambda: _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16"))
+            lambda: _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16"),
+            (q.shape[0], heads, nq, nk, d))
     return out
 
 

@@ -39,6 +39,11 @@ extern "C" {
 
 #define SASPA_ACT_NONE 0
 #define SASPA_ACT_SILU 1
+/* saspa_gemm only, bf16 only: fused GEGLU epilogue.  N = 2F columns are computed, F are
+ * stored: out[m][f] = val * gelu_erf(gate).  The weight rows (and bias) must be packed per
+ * output tile of BN columns (BN = 160 if N % 160 == 0 else 128; N % BN == 0 required):
+ * tile t holds features [t*BN/2, (t+1)*BN/2) -- their value rows first, then their gate rows. */
+#define SASPA_ACT_GEGLU 3
 
 /* ---- implicit-GEMM convolution / linear ----------------------------------
  * out[m][n] = act( alpha * (sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n]) ) + residual[m][n]
@@ -78,6 +83,11 @@ typedef struct SaspaGemmParams {
   long long sa1, sa2;        /* element strides of a0 */
   long long sw1, sw2;        /* element strides of w */
   long long so1, so2;        /* element strides of out (and residual) */
+  /* split-K (optional): ksplit > 1 with a workspace of ksplit*M*N floats makes the library
+   * slice the K range over ksplit workgroups per tile (fp32 partial slabs + one reduce /
+   * epilogue launch).  Ignored when workspace is NULL, for batched problems or N % 4 != 0. */
+  int ksplit;
+  float* workspace;
 } SaspaGemmParams;
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 

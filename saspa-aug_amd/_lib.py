@@ -20,7 +20,7 @@ class GemmParams(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int), ("alpha", C.c_float), ("act", C.c_int),
         ("out", C.c_void_p), ("ldo", C.c_int), ("nb1", C.c_int), ("nb2", C.c_int),
         ("sa1", C.c_longlong), ("sa2", C.c_longlong), ("sw1", C.c_longlong), ("sw2", C.c_longlong),
-        ("so1", C.c_longlong), ("so2", C.c_longlong),
+        ("so1", C.c_longlong), ("so2", C.c_longlong), ("ksplit", C.c_int), ("workspace", C.c_void_p),
     ]
 
 

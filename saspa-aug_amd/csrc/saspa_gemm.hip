@@ -13,14 +13,16 @@
 //   * the MFMA computes D^T (weights as the A operand) so every lane ends up with 4
 //     consecutive output channels of one pixel: 8/16-byte epilogue accesses for bias,
 //     time-embedding row vector, residual and the store.
+//   * tile shapes: 128x160 when N is a multiple of 160 (the SD-1.5 widths 320/640/1280 and
+//     their multiples tile exactly), else 128x128; 128x32 for skinny N; 64x64 when there
+//     are too few tiles to fill 256 CUs.
+//   * tiles are enumerated so that the 8 XCDs each own a contiguous range (blocks b and
+//     b+8 share an XCD): neighbouring tiles (same activation rows) hit the same L2.
+//   * split-K (gridDim.y slices of the K range, fp32 partial slabs in a caller workspace +
+//     one reduce/epilogue launch) for the deep levels where M is 1-4 K rows but K is 6-23 K.
 #include "common.h"
 
 namespace {
-
-struct RowState {
-  int iy0, ix0;   // top-left input coordinate of the window (virtual, i.e. after upsample)
-  int pix0;       // b * hin * win
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -45,7 +47,9 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int WM, int WN>
+// PW: pointwise (1x1, stride 1, no pad, no upsample): the A row of output pixel m is input
+// pixel m -- no window arithmetic at all.
+template <typename T, int WM, int WN, bool PW>
 __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int EPC = Elem<T>::EPC;
@@ -59,7 +63,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bn = blockIdx.x, bm = blockIdx.y;
+
+  // ---- XCD-aware tile order (bijective for any tile count) ----
+  const int nbn = (p.N + BN - 1) / BN;
+  int tile;
+  {
+    const int T_ = gridDim.x, L = blockIdx.x;
+    const int qd = T_ >> 3, rr = T_ & 7, xcd = L & 7, idx = L >> 3;
+    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
+  }
+  const int bm = tile / nbn, bn = tile - bm * nbn;
   const int z = blockIdx.z;
   const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
 
@@ -68,26 +81,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
   const long long ooff = i1 * p.so1 + i2 * p.so2;
 
+  // ---- K range of this block (split-K over gridDim.y) ----
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * kt_per;
+  const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
+
   // ---- loader state ----
   const int kc = tid & 7;
   const int r0 = tid >> 3;  // rows r0 + 32*i
   const int hw = p.hout * p.wout;
-  RowState rs[A_CH];
+  int row_a[A_CH], row_b[A_CH], row_c[A_CH];  // PW: (m, -, -);  window: (iy0, ix0, pix0)
+  if (PW) {
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int m = bm * BM + r0 + 32 * i;
-    if (m < p.M) {
-      const int b = m / hw;
-      const int rem = m - b * hw;
-      const int oy = rem / p.wout;
-      const int ox = rem - oy * p.wout;
-      rs[i].iy0 = oy * p.stride - p.pad;
-      rs[i].ix0 = ox * p.stride - p.pad;
-      rs[i].pix0 = b * p.hin * p.win;
-    } else {
-      rs[i].iy0 = -(1 << 28);
-      rs[i].ix0 = -(1 << 28);
-      rs[i].pix0 = 0;
+    for (int i = 0; i < A_CH; ++i) {
+      const int m = bm * BM + r0 + 32 * i;
+      row_a[i] = (m < p.M) ? m : -1;
+      row_b[i] = row_c[i] = 0;
+    }
+  } else {
+    // first row by division, the following rows (+32 each) by carry propagation
+    int m = bm * BM + r0;
+    int b = m / hw;
+    int rem = m - b * hw;
+    int oy = rem / p.wout;
+    int ox = rem - oy * p.wout;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      if (m < p.M) {
+        row_a[i] = oy * p.stride - p.pad;
+        row_b[i] = ox * p.stride - p.pad;
+        row_c[i] = b * p.hin * p.win;
+      } else {
+        row_a[i] = row_b[i] = -(1 << 28);
+        row_c[i] = 0;
+      }
+      m += 32;
+      ox += 32;
+      while (ox >= p.wout) { ox -= p.wout; ++oy; }
+      while (oy >= p.hout) { oy -= p.hout; ++b; }
     }
   }
   const T* wrow[B_CH];
@@ -99,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   const int ctot = p.c0 + p.c1;
   const int hv = p.upsample ? 2 * p.hin : p.hin;
   const int wv = p.upsample ? 2 * p.win : p.win;
-  int k = kc * EPC;
+  int k = kt0 * BK + kc * EPC;
   int tap = k / ctot;
   int c = k - tap * ctot;
   int dy = tap / p.kw;
@@ -115,11 +147,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
     if (c < p.c0) { src = a0; ld = p.lda0; cc = c; } else { src = a1; ld = p.lda1; cc = c - p.c0; }
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int iy = rs[i].iy0 + dy, ix = rs[i].ix0 + dx;
-      const bool inb = kvalid && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
-      if (p.upsample) { iy >>= 1; ix >>= 1; }
-      const long long off = (long long)(rs[i].pix0 + iy * p.win + ix) * ld + cc;
-      ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
+      if (PW) {
+        const bool inb = kvalid && row_a[i] >= 0;
+        const long long off = (long long)row_a[i] * ld + cc;
+        ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
+      } else {
+        int iy = row_a[i] + dy, ix = row_b[i] + dx;
+        const bool inb = kvalid && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const long long off = (long long)(row_c[i] + iy * p.win + ix) * ld + cc;
+        ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
@@ -173,9 +211,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile();
-  store_tile(0);
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1) < nk;
@@ -185,9 +224,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds out[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) ----
+  // ---- split-K: raw fp32 partial slab, epilogue happens in the reduce launch ----
+  if (gridDim.y > 1) {
+    float* ws = p.workspace + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int m = bm * BM + wm * (16 * WM) + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = bn * BN + wn * (16 * WN) + j * 16 + fg * 4;
+        if (n >= p.N) continue;   // N % 4 == 0 is required with split-K
+        *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue ----
   T* out = reinterpret_cast<T*>(p.out) + ooff;
   const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + ooff : nullptr;
+  const bool geglu = p.act == SASPA_ACT_GEGLU;
+  // bf16 fast path: the tile goes through LDS so that global stores (and the residual
+  // read) are whole 16-byte chunks of contiguous output rows instead of 8-byte fragments
+  // at a row stride (partial cache lines).  GEGLU pairs the value / gate halves there.
+  const bool staged = sizeof(T) == 2 && (p.N % 8) == 0 && (p.ldo % 8) == 0 && (!res || (p.ldr % 8) == 0) &&
+                      (!geglu || (p.N % BN) == 0);
+  if (staged) {
+    constexpr int CP = BN + 8;                       // LDS row pitch in elements (16-byte pad)
+    T* ct = reinterpret_cast<T*>(lds);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int mrow = wm * (16 * WM) + i * 16 + frow;
+      const int m = bm * BM + mrow;
+      const float* rv = nullptr;
+      if (p.rowvec && m < p.M) rv = p.rowvec + (long long)(m / hw) * p.ldrv;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int ncol = wn * (16 * WN) + j * 16 + fg * 4;
+        const int n = bn * BN + ncol;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (n < p.N) {   // N % 8 == 0: a 4-vector never straddles N
+          if (p.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (rv) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] *= p.alpha;
+            if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
+          }
+        }
+        Elem<T>::store4(ct + mrow * CP + ncol, v);
+      }
+    }
+    __syncthreads();
+    if (!geglu) {
+      constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
+      for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, ch = q - row * CPR;
+        const int m = bm * BM + row, n = bn * BN + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
+        if (res) {
+          float a[8], b[8];
+          unpack8(__builtin_bit_cast(uint4, c4), a);
+          Elem<bf16_t>::load_chunk(reinterpret_cast<const bf16_t*>(res) + (long long)m * p.ldr + n, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          c4 = __builtin_bit_cast(u32x4, pack8(a));
+        }
+        *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
+      }
+    } else {
+      // tile columns [0, BN/2) are values, [BN/2, BN) the matching gates (weights packed so)
+      constexpr int HB = BN / 2, CPR = HB / 8;
+      for (int q = tid; q < BM * CPR; q += 256) {
+        const int row = q / CPR, ch = q - row * CPR;
+        const int m = bm * BM + row, f = bn * HB + ch * 8;
+        if (m >= p.M) continue;
+        float a[8], g[8];
+        unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + ch * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + HB + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+        *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + f) = pack8(a);
+      }
+    }
+    return;
+  }
+  // generic path (fp32 parity mode, odd N): lane holds out[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4)
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int m = bm * BM + wm * (16 * WM) + i * 16 + frow;
@@ -235,22 +366,76 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   }
 }
 
+// split-K reduce + epilogue: out = act(alpha*(sum_s ws[s] + bias + rowvec)) + residual
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SaspaGemmParams p, int ksplit) {
+  const int n4 = p.N >> 2;
+  const long long total = (long long)p.M * n4;
+  const long long slab = (long long)p.M * p.N;
+  const int hw = p.hout * p.wout;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.residual);
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int m = (int)(it / n4);
+    const int n = (int)(it - (long long)m * n4) * 4;
+    float4 a = *reinterpret_cast<const float4*>(p.workspace + (long long)m * p.N + n);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(p.workspace + s * slab + (long long)m * p.N + n);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (p.rowvec) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)(m / hw) * p.ldrv + n);
+      v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] *= p.alpha;
+      if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
+    }
+    if (res) {
+      float rr[4];
+      Elem<T>::load4(res + (long long)m * p.ldr + n, rr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += rr[r];
+    }
+    Elem<T>::store4(out + (long long)m * p.ldo + n, v);
+  }
+}
+
 template <typename T, int WM, int WN>
-int launch(const SaspaGemmParams& p, hipStream_t s) {
+int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb1 * p.nb2);
-  hipLaunchKernelGGL((gemm_kernel<T, WM, WN>), grid, dim3(256), 0, s, p);
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  dim3 grid(tiles, ksplit, p.nb1 * p.nb2);
+  const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
+  if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p);
   SASPA_CHECK_LAUNCH();
+  if (ksplit > 1) {
+    long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
+    SASPA_CHECK_LAUNCH();
+  }
   return 0;
 }
 
 template <typename T>
 int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const long long nb = (long long)p.nb1 * p.nb2;
-  if (p.N <= 32) return launch<T, 4, 1>(p, s);
-  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
-  if (tiles128 >= 192 && p.N > 64) return launch<T, 4, 4>(p, s);
-  return launch<T, 2, 2>(p, s);
+  int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
+  const bool n160 = (p.N % 160) == 0;
+  if (p.act == SASPA_ACT_GEGLU) return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
+  if (p.N <= 32) return launch<T, 4, 1>(p, s, 1);
+  const int bn = n160 ? 160 : 128;
+  const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
+  if (tiles >= 160 && p.N > 64) return n160 ? launch<T, 4, 5>(p, s, ksplit) : launch<T, 4, 4>(p, s, ksplit);
+  return launch<T, 2, 2>(p, s, ksplit);
 }
 
 }  // namespace
@@ -276,13 +461,24 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (p.rowvec && (p.ldrv % 4)) return SASPA_EALIGN;
   if (p.K != p.kh * p.kw * (p.c0 + p.c1)) return SASPA_ERANGE;
   if ((long long)p.batch * p.hout * p.wout != p.M) return SASPA_ERANGE;
-  if (p.lda0 < p.c0 || (p.c1 > 0 && p.lda1 < p.c1) || p.ldw < p.K || p.ldo < p.N) return SASPA_ERANGE;
+  if (p.lda0 < p.c0 || (p.c1 > 0 && p.lda1 < p.c1) || p.ldw < p.K) return SASPA_ERANGE;
+  if (p.act != SASPA_ACT_GEGLU && p.ldo < p.N) return SASPA_ERANGE;
   // the window of every output pixel must come from the declared input extent
   {
     const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
     if ((p.hout - 1) * p.stride - p.pad >= hv || (p.wout - 1) * p.stride - p.pad >= wv) return SASPA_ERANGE;
   }
   if ((long long)p.batch * p.hin * p.win >= (1ll << 31)) return SASPA_ERANGE;
+  if (p.ksplit < 0 || p.ksplit > 64) return SASPA_ERANGE;
+  if (p.act == SASPA_ACT_GEGLU) {
+    // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)
+    const int bn = (p.N % 160) == 0 ? 160 : 128;
+    if (p.dtype != SASPA_BF16 || p.N % bn || p.residual || p.ldo % 8 || p.ldo < p.N / 2) return SASPA_ERANGE;
+    p.ksplit = 1;
+  } else if (p.act != SASPA_ACT_NONE && p.act != SASPA_ACT_SILU) {
+    return SASPA_EINVAL;
+  }
+  if (p.ksplit > 1 && p.workspace && !aligned16(p.workspace)) return SASPA_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.dtype == SASPA_BF16) return dispatch<bf16_t>(p, s);
   return dispatch<float>(p, s);

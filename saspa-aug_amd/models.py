@@ -146,14 +146,21 @@ class _Net:
             pk.norm(f"{t}.{n}")
         pk.attn(t + ".attn1", True)
         pk.attn(t + ".attn2", False)
-        pk.linear(t + ".ff.net.0.proj")
+        packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
+            if self.dtype == torch.bfloat16 else None
+        if packed is not None:          # bf16: GEGLU fused into the projection's epilogue
+            self.p[t + ".ff.net.0.proj.w"] = packed[0].to(self.dev, self.dtype)
+            self.p[t + ".ff.net.0.proj.b"] = _f32(packed[1], self.dev)
+            self.fused_geglu.add(t)
+        else:
+            pk.linear(t + ".ff.net.0.proj")
         pk.linear(t + ".ff.net.2")
         pk.conv(pfx + ".proj_out")
         self.transformers.append(pfx)
 
     def _pack_encoder(self):
         cfg, pk = self.cfg, self.pk
-        self.resnets_with_temb, self.transformers = [], []
+        self.resnets_with_temb, self.transformers, self.fused_geglu = [], [], set()
         pk.conv("conv_in")
         pk.linear("time_embedding.linear_1", torch.float32)
         pk.linear("time_embedding.linear_2", torch.float32)
@@ -232,7 +239,10 @@ class _Net:
         h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
         # GEGLU feed-forward
         n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
-        ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
+        if t in self.fused_geglu:
+            ff = ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU)
+        else:
+            ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
         h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
         return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x)
 

@@ -13,6 +13,7 @@ from . import _lib
 
 ACT_NONE, ACT_SILU = 0, 1
 ACT_QUICK_GELU = 2  # saspa_activation only
+ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
 
 
 # Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)
@@ -73,6 +74,28 @@ def round8(n):
     return (n + 7) // 8 * 8
 
 
+def _ksplit(m, n, k, dtype):
+    """Split-K factor for the deep UNet levels (M of 1-4 K rows, K of 6-23 K): enough K slices
+    to give the 256 CUs about two workgroups each; 1 (off) for everything else."""
+    bk = 64 if dtype == torch.bfloat16 else 32
+    bn = 160 if n % 160 == 0 else 128
+    tiles = -(-m // 128) * -(-n // bn)
+    ktiles = -(-k // bk)
+    if n <= 64 or n % 4 or tiles >= 512 or ktiles < 32:
+        return 1
+    return max(1, min(8, -(-512 // tiles), ktiles // 8))
+
+
+def _set_splitk(p, m, n, k, t):
+    ks = _ksplit(m, n, k, t.dtype)
+    if ks > 1:
+        ws = torch.empty((ks * m * n,), device=t.device, dtype=torch.float32)
+        p.ksplit, p.workspace = ks, C.c_void_p(ws.data_ptr())
+        return ws           # keep alive until the launch is enqueued
+    p.ksplit, p.workspace = 1, None
+    return None
+
+
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
          residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
@@ -107,6 +130,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.alpha, p.act = float(alpha), int(act)
     p.out, p.ldo = _ptr(out), _pitch4(out)
     p.nb1 = p.nb2 = 1
+    _ws = _set_splitk(p, p.M, p.N, p.K, x)  # noqa: F841
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
             (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
     return out
@@ -121,8 +145,8 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     m = x2.shape[0]
     n = w.shape[0]
     if out is None:
-        nc = round8(n)
-        out = (torch.zeros if nc != n else torch.empty)((m, nc), device=x.device, dtype=x.dtype)
+        nc = round8(n // 2 if act == ACT_GEGLU else n)
+        out = (torch.zeros if (nc != n and act != ACT_GEGLU) else torch.empty)((m, nc), device=x.device, dtype=x.dtype)
     o2 = out.view(-1, out.shape[-1]) if out.dim() != 2 else out
     r2 = None if residual is None else (residual.reshape(-1, residual.shape[-1]) if residual.dim() != 2 else residual)
     p = _lib.GemmParams()
@@ -139,8 +163,11 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.ldr = 0 if r2 is None else (r2.stride(0) if m > 1 else max(n, r2.stride(0)))
     p.alpha, p.act = float(alpha), int(act)
     p.out = _ptr(o2)
-    p.ldo = o2.stride(0) if m > 1 else max(n, o2.stride(0))
+    p.ldo = o2.stride(0) if m > 1 else max(o2.shape[-1], o2.stride(0))
     p.nb1 = p.nb2 = 1
+    _ws = _set_splitk(p, m, n, k, x) if act != ACT_GEGLU else None  # noqa: F841
+    if act == ACT_GEGLU:
+        p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),
             (m, n, k, 0, 1, 0, False))
     if x.dim() != 2 and out.dim() == 2:
@@ -169,6 +196,7 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.sa1, p.sa2 = sa
     p.sw1, p.sw2 = sw
     p.so1, p.so2 = so
+    p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k * nb1 * nb2,
             lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"), (m, n, k, -nb1 * nb2, 1, 0, False))
     return out

@@ -215,3 +215,25 @@ def pack_linear(w, k_pad=None):
     if kp != k:
         w = torch.nn.functional.pad(w, (0, kp - k))
     return w.contiguous()
+
+
+def geglu_tile(n):
+    """Output-tile width the GEMM picks for N columns (must mirror csrc/saspa_gemm.hip)."""
+    return 160 if n % 160 == 0 else 128
+
+
+def pack_geglu(w, b):
+    """GEGLU.proj weight [2F, K] / bias [2F] -> rows regrouped per output tile so the fused
+    epilogue finds each feature's value and gate in the same tile: tile t = [values of features
+    t*BN/2 .. (t+1)*BN/2), then their gates].  Returns None when 2F is not a whole number of tiles."""
+    n = w.shape[0]
+    f = n // 2
+    bn = geglu_tile(n)
+    if n % bn:
+        return None
+    half = bn // 2
+    idx = []
+    for t in range(n // bn):
+        idx += list(range(t * half, (t + 1) * half)) + list(range(f + t * half, f + (t + 1) * half))
+    idx = torch.tensor(idx)
+    return w[idx].contiguous(), b[idx].contiguous()

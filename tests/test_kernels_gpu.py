@@ -25,7 +25,11 @@ def _rand(*shape, seed=0, scale=1.0):
 
 # ------------------------------------------------------------------ linear / GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("m,k,n", [(300, 320, 960), (77, 768, 320), (1, 320, 1280), (129, 64, 40), (4096, 1280, 320)])
+@pytest.mark.parametrize("m,k,n", [(300, 320, 960), (77, 768, 320), (1, 320, 1280), (129, 64, 40), (4096, 1280, 320),
+                                   (8192, 320, 640),      # 128x160 tiles, pointwise path, > 160 tiles
+                                   (8200, 128, 512),      # 128x128 tiles, ragged M
+                                   (1024, 4096, 1280),    # split-K (8 slices) + 128x160 tiles
+                                   (640, 2560, 192)])     # split-K with 128x128 tiles, ragged N tile
 def test_linear(dev, dtype, m, k, n):
     x = q(_rand(m, k, seed=1), dtype)
     w = q(_rand(n, k, seed=2, scale=1 / math.sqrt(k)), dtype)
@@ -36,6 +40,21 @@ def test_linear(dev, dtype, m, k, n):
                      act=ops.ACT_SILU)
     assert out.shape == (m, ops.round8(n))
     assert_close(out.float().cpu()[:, :n], ref, dtype, what=f"linear {m}x{k}x{n}")
+
+
+@pytest.mark.parametrize("m,k,f", [(4096, 320, 1280), (300, 64, 128), (1024, 128, 640)])
+def test_linear_fused_geglu(dev, m, k, f):
+    """GEGLU fused into the projection epilogue (value / gate rows regrouped per output tile)."""
+    dtype = torch.bfloat16
+    x = q(_rand(m, k, seed=50), dtype)
+    w = q(_rand(2 * f, k, seed=51, scale=1 / math.sqrt(k)), dtype)
+    b = _rand(2 * f, seed=52)
+    h = x @ w.t() + b
+    ref = h[:, :f] * F.gelu(h[:, f:])
+    wp, bp = W.pack_geglu(w, b)
+    out = ops.linear(x.to(dev, dtype), wp.to(dev, dtype), bp.to(dev), act=ops.ACT_GEGLU)
+    assert out.shape == (m, f)
+    assert_close(out.float().cpu(), ref, dtype, what=f"fused geglu {m}x{k}x{f}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -75,6 +94,9 @@ CONV_CASES = [
     (2, 8, 8, 128, 128, 1, 1, False),    # 1x1
     (2, 32, 32, 3, 16, 3, 1, False),     # cond-embedding conv_in
     (2, 32, 32, 16, 32, 3, 2, False),
+    (2, 64, 64, 64, 640, 3, 1, False),   # 128x160 tiles, window path, 256 tiles
+    (1, 16, 16, 512, 320, 3, 1, False),  # split-K conv (K = 4608)
+    (2, 16, 16, 256, 640, 3, 1, True),   # split-K + upsample
 ]
 
 

@@ -8,8 +8,9 @@
 //   * K-tile = 128 bytes per row for both dtypes (64 bf16 / 32 fp32): the LDS image, its
 //     XOR swizzle (chunk ^ (row & 7): conflict-free for ds_read_b128 row reads) and the
 //     staging code are shared between the two precisions.
-//   * register-staged double buffering (global -> VGPR issued before the MFMA block of the
-//     current tile, VGPR -> LDS after it, one barrier per K-tile).
+//   * register-staged pipeline, two staging register sets: while tile t is multiplied out of
+//     LDS (2 stages), the global loads of tiles t+1 and t+2 are in flight; VGPR -> LDS after
+//     the MFMA block, one barrier per K-tile.
 //   * the MFMA computes D^T (weights as the A operand) so every lane ends up with 4
 //     consecutive output channels of one pixel: 8/16-byte epilogue accesses for bias,
 //     time-embedding row vector, residual and the store.
@@ -20,6 +21,8 @@
 //     b+8 share an XCD): neighbouring tiles (same activation rows) hit the same L2.
 //   * split-K (gridDim.y slices of the K range, fp32 partial slabs in a caller workspace +
 //     one reduce/epilogue launch) for the deep levels where M is 1-4 K rows but K is 6-23 K.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -50,7 +53,7 @@ template <> struct Mma<float> {
 // PW: pointwise (1x1, stride 1, no pad, no upsample): the A row of output pixel m is input
 // pixel m -- no window arithmetic at all.
 template <typename T, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -137,10 +140,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
   int dy = tap / p.kw;
   int dx = tap - dy * p.kw;
 
-  u32x4 ra[A_CH], rb[B_CH];
+  // two register staging sets: while tile t is being multiplied out of LDS, tiles t+1 and
+  // t+2 are in flight from global memory (two K-tiles of loads outstanding per workgroup)
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  auto load_tile = [&]() __attribute__((always_inline)) {
+  auto load_tile = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
     const bool kvalid = k < p.K;
     const T* src;
     int ld, cc;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
       if (++dx == p.kw) { dx = 0; ++dy; }
     }
   };
-  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+  auto store_tile = [&](int stage, const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
     u32x4* la = lds + stage * STAGE;
     u32x4* lb = la + BM * 8;
     const int sw = kc ^ (r0 & 7);
@@ -211,16 +216,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
     }
   };
 
-  if (nk > 0) {
-    load_tile();
-    store_tile(0);
-  }
+  if (nk > 0) load_tile(ra0, rb0);
+  if (nk > 1) load_tile(ra1, rb1);
+  if (nk > 0) store_tile(0, ra0, rb0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) load_tile();
-    compute(kt & 1);
-    if (more) store_tile((kt + 1) & 1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even tile kt: LDS stage 0; set 0 is free -> prefetch tile kt+2; set 1 (tile kt+1) -> stage 1
+    if (kt + 2 < nk) load_tile(ra0, rb0);
+    compute(0);
+    if (kt + 1 < nk) store_tile(1, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd tile kt+1: LDS stage 1; set 1 is free -> prefetch tile kt+3; set 0 (tile kt+2) -> stage 0
+    if (kt + 3 < nk) load_tile(ra1, rb1);
+    compute(1);
+    if (kt + 2 < nk) store_tile(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -275,10 +285,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
             v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] *= p.alpha;
-            if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
-          }
+          for (int r = 0; r < 4; ++r) v[r] *= p.alpha;   // SiLU (if any) is applied in the read phase
         }
         Elem<T>::store4(ct + mrow * CP + ncol, v);
       }
@@ -291,12 +298,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const SaspaGemmParams p) {
         const int m = bm * BM + row, n = bn * BN + ch * 8;
         if (m >= p.M || n >= p.N) continue;
         u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
-        if (res) {
-          float a[8], b[8];
+        if (res || p.act == SASPA_ACT_SILU) {
+          float a[8];
           unpack8(__builtin_bit_cast(uint4, c4), a);
-          Elem<bf16_t>::load_chunk(reinterpret_cast<const bf16_t*>(res) + (long long)m * p.ldr + n, b);
+          if (p.act == SASPA_ACT_SILU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += b[e];
+            for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
+          }
+          if (res) {
+            float b[8];
+            Elem<bf16_t>::load_chunk(reinterpret_cast<const bf16_t*>(res) + (long long)m * p.ldr + n, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+          }
           c4 = __builtin_bit_cast(u32x4, pack8(a));
         }
         *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
@@ -434,6 +448,8 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   if (p.N <= 32) return launch<T, 4, 1>(p, s, 1);
   const int bn = n160 ? 160 : 128;
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
+  static const int force_small = getenv("SASPA_GEMM_SMALLK") ? atoi(getenv("SASPA_GEMM_SMALLK")) : 0;   // experiment knob
+  if (force_small && p.K <= force_small) return launch<T, 2, 2>(p, s, ksplit);
   if (tiles >= 160 && p.N > 64) return n160 ? launch<T, 4, 5>(p, s, ksplit) : launch<T, 4, 4>(p, s, ksplit);
   return launch<T, 2, 2>(p, s, ksplit);
 }

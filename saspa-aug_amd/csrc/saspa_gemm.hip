@@ -8,6 +8,8 @@
 //   * K-tile = 128 bytes per row for both dtypes (64 bf16 / 32 fp32): the LDS image, its
 //     XOR swizzle (chunk ^ (row & 7): conflict-free for ds_read_b128 row reads) and the
 //     staging code are shared between the two precisions.
+//   * operands are fetched with raw buffer loads (hardware bounds check -> zeros) whose
+//     per-lane offsets are fixed per output tile; the K advance lives in scalar registers.
 //   * register-staged pipeline, two staging register sets: while tile t is multiplied out of
 //     LDS (2 stages), the global loads of tiles t+1 and t+2 are in flight; VGPR -> LDS after
 //     the MFMA block, one barrier per K-tile.
@@ -26,6 +28,18 @@
 #include "common.h"
 
 namespace {
+
+// Raw buffer loads: 32-bit per-lane byte offset + scalar byte offset against a 128-bit
+// descriptor; an offset >= num_records (2 GiB here) returns zeros -- that is how M / N / halo
+// padding is produced with no branch and no zero-fill (kInvalid below).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kInvalid = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -50,230 +64,54 @@ template <> struct Mma<float> {
   }
 };
 
-// PW: pointwise (1x1, stride 1, no pad, no upsample): the A row of output pixel m is input
-// pixel m -- no window arithmetic at all.
-template <typename T, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
+// ---- shared epilogue of both kernel variants ------------------------------------------
+// split-K: raw fp32 slab.  bf16: the tile goes through LDS so that global stores (and the
+// residual read) are whole 16-byte chunks of contiguous output rows; GEGLU pairs the value /
+// gate halves there.  fp32 parity mode / odd N: direct per-lane path.
+// The caller guarantees every wave has finished reading the K-loop's LDS stages.
+template <typename T, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&acc)[WM][WN], u32x4* lds, const int cbm,
+                                              const int cbn, const long long ooff) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
-  constexpr int EPC = Elem<T>::EPC;
-  constexpr int BK = 8 * EPC;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
-  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
-  constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
-  __shared__ u32x4 lds[2 * STAGE];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- XCD-aware tile order (bijective for any tile count) ----
-  const int nbn = (p.N + BN - 1) / BN;
-  int tile;
-  {
-    const int T_ = gridDim.x, L = blockIdx.x;
-    const int qd = T_ >> 3, rr = T_ & 7, xcd = L & 7, idx = L >> 3;
-    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
-  }
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int z = blockIdx.z;
-  const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
-
-  const T* a0 = reinterpret_cast<const T*>(p.a0) + (i1 * p.sa1 + i2 * p.sa2);
-  const T* a1 = reinterpret_cast<const T*>(p.a1);
-  const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
-  const long long ooff = i1 * p.so1 + i2 * p.so2;
-
-  // ---- K range of this block (split-K over gridDim.y) ----
-  const int nk_all = (p.K + BK - 1) / BK;
-  const int kt_per = (nk_all + gridDim.y - 1) / gridDim.y;
-  const int kt0 = blockIdx.y * kt_per;
-  const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
-
-  // ---- loader state ----
-  const int kc = tid & 7;
-  const int r0 = tid >> 3;  // rows r0 + 32*i
-  const int hw = p.hout * p.wout;
-  int row_a[A_CH], row_b[A_CH], row_c[A_CH];  // PW: (m, -, -);  window: (iy0, ix0, pix0)
-  if (PW) {
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int m = bm * BM + r0 + 32 * i;
-      row_a[i] = (m < p.M) ? m : -1;
-      row_b[i] = row_c[i] = 0;
-    }
-  } else {
-    // first row by division, the following rows (+32 each) by carry propagation
-    int m = bm * BM + r0;
-    int b = m / hw;
-    int rem = m - b * hw;
-    int oy = rem / p.wout;
-    int ox = rem - oy * p.wout;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      if (m < p.M) {
-        row_a[i] = oy * p.stride - p.pad;
-        row_b[i] = ox * p.stride - p.pad;
-        row_c[i] = b * p.hin * p.win;
-      } else {
-        row_a[i] = row_b[i] = -(1 << 28);
-        row_c[i] = 0;
-      }
-      m += 32;
-      ox += 32;
-      while (ox >= p.wout) { ox -= p.wout; ++oy; }
-      while (oy >= p.hout) { oy -= p.hout; ++b; }
-    }
-  }
-  const T* wrow[B_CH];
-#pragma unroll
-  for (int i = 0; i < B_CH; ++i) {
-    const int n = bn * BN + r0 + 32 * i;
-    wrow[i] = (n < p.N) ? (w + (long long)n * p.ldw) : nullptr;
-  }
-  const int ctot = p.c0 + p.c1;
-  const int hv = p.upsample ? 2 * p.hin : p.hin;
-  const int wv = p.upsample ? 2 * p.win : p.win;
-  int k = kt0 * BK + kc * EPC;
-  int tap = k / ctot;
-  int c = k - tap * ctot;
-  int dy = tap / p.kw;
-  int dx = tap - dy * p.kw;
-
-  // two register staging sets: while tile t is being multiplied out of LDS, tiles t+1 and
-  // t+2 are in flight from global memory (two K-tiles of loads outstanding per workgroup)
-  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  auto load_tile = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
-    const bool kvalid = k < p.K;
-    const T* src;
-    int ld, cc;
-    if (c < p.c0) { src = a0; ld = p.lda0; cc = c; } else { src = a1; ld = p.lda1; cc = c - p.c0; }
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      if (PW) {
-        const bool inb = kvalid && row_a[i] >= 0;
-        const long long off = (long long)row_a[i] * ld + cc;
-        ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
-      } else {
-        int iy = row_a[i] + dy, ix = row_b[i] + dx;
-        const bool inb = kvalid && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        const long long off = (long long)(row_c[i] + iy * p.win + ix) * ld + cc;
-        ra[i] = inb ? *reinterpret_cast<const u32x4*>(src + off) : zero4;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      rb[i] = (kvalid && wrow[i] != nullptr) ? *reinterpret_cast<const u32x4*>(wrow[i] + k) : zero4;
-    }
-    k += BK;
-    c += BK;
-    while (c >= ctot) {
-      c -= ctot;
-      if (++dx == p.kw) { dx = 0; ++dy; }
-    }
-  };
-  auto store_tile = [&](int stage, const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
-    u32x4* la = lds + stage * STAGE;
-    u32x4* lb = la + BM * 8;
-    const int sw = kc ^ (r0 & 7);
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) la[(r0 + 32 * i) * 8 + sw] = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) lb[(r0 + 32 * i) * 8 + sw] = rb[i];
-  };
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, fg = lane >> 4;
-  auto compute = [&](int stage) __attribute__((always_inline)) {
-    const u32x4* la = lds + stage * STAGE;
-    const u32x4* lb = la + BM * 8;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int chunk = kk * 4 + fg;
-      u32x4 xa[WM], wb[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int row = wm * (16 * WM) + i * 16 + frow;
-        xa[i] = la[row * 8 + (chunk ^ (row & 7))];
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int row = wn * (16 * WN) + j * 16 + frow;
-        wb[j] = lb[row * 8 + (chunk ^ (row & 7))];
-      }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) Mma<T>::run(wb[j], xa[i], acc[i][j]);
-    }
-  };
-
-  if (nk > 0) load_tile(ra0, rb0);
-  if (nk > 1) load_tile(ra1, rb1);
-  if (nk > 0) store_tile(0, ra0, rb0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even tile kt: LDS stage 0; set 0 is free -> prefetch tile kt+2; set 1 (tile kt+1) -> stage 1
-    if (kt + 2 < nk) load_tile(ra0, rb0);
-    compute(0);
-    if (kt + 1 < nk) store_tile(1, ra1, rb1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    // odd tile kt+1: LDS stage 1; set 1 is free -> prefetch tile kt+3; set 0 (tile kt+2) -> stage 0
-    if (kt + 3 < nk) load_tile(ra1, rb1);
-    compute(1);
-    if (kt + 2 < nk) store_tile(0, ra0, rb0);
-    __syncthreads();
-  }
-
-  // ---- split-K: raw fp32 partial slab, epilogue happens in the reduce launch ----
-  if (gridDim.y > 1) {
-    float* ws = p.workspace + (long long)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const int m = bm * BM + wm * (16 * WM) + i * 16 + frow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int n = bn * BN + wn * (16 * WN) + j * 16 + fg * 4;
-        if (n >= p.N) continue;   // N % 4 == 0 is required with split-K
-        *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue ----
+  const int hw = p.hout * p.wout;
   T* out = reinterpret_cast<T*>(p.out) + ooff;
   const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + ooff : nullptr;
   const bool geglu = p.act == SASPA_ACT_GEGLU;
-  // bf16 fast path: the tile goes through LDS so that global stores (and the residual
-  // read) are whole 16-byte chunks of contiguous output rows instead of 8-byte fragments
-  // at a row stride (partial cache lines).  GEGLU pairs the value / gate halves there.
   const bool staged = sizeof(T) == 2 && (p.N % 8) == 0 && (p.ldo % 8) == 0 && (!res || (p.ldr % 8) == 0) &&
                       (!geglu || (p.N % BN) == 0);
-  if (staged) {
+    if (gridDim.y > 1) {
+      // ---- split-K: raw fp32 partial slab, epilogue happens in the reduce launch ----
+      float* ws = p.workspace + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int m = cbm * BM + wm * (16 * WM) + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int n = cbn * BN + wn * (16 * WN) + j * 16 + fg * 4;
+          if (n >= p.N) continue;   // N % 4 == 0 is required with split-K
+          *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+    } else if (staged) {
     constexpr int CP = BN + 8;                       // LDS row pitch in elements (16-byte pad)
     T* ct = reinterpret_cast<T*>(lds);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int mrow = wm * (16 * WM) + i * 16 + frow;
-      const int m = bm * BM + mrow;
+      const int m = cbm * BM + mrow;
       const float* rv = nullptr;
       if (p.rowvec && m < p.M) rv = p.rowvec + (long long)(m / hw) * p.ldrv;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int ncol = wn * (16 * WN) + j * 16 + fg * 4;
-        const int n = bn * BN + ncol;
+        const int n = cbn * BN + ncol;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         if (n < p.N) {   // N % 8 == 0: a 4-vector never straddles N
           if (p.bias) {
@@ -295,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
       constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
       for (int q = tid; q < BM * CPR; q += 256) {
         const int row = q / CPR, ch = q - row * CPR;
-        const int m = bm * BM + row, n = bn * BN + ch * 8;
+        const int m = cbm * BM + row, n = cbn * BN + ch * 8;
         if (m >= p.M || n >= p.N) continue;
         u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
         if (res || p.act == SASPA_ACT_SILU) {
@@ -320,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
       constexpr int HB = BN / 2, CPR = HB / 8;
       for (int q = tid; q < BM * CPR; q += 256) {
         const int row = q / CPR, ch = q - row * CPR;
-        const int m = bm * BM + row, f = bn * HB + ch * 8;
+        const int m = cbm * BM + row, f = cbn * HB + ch * 8;
         if (m >= p.M) continue;
         float a[8], g[8];
         unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + ch * 8), a);
@@ -330,18 +168,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
         *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + f) = pack8(a);
       }
     }
-    return;
-  }
+    } else {
   // generic path (fp32 parity mode, odd N): lane holds out[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4)
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    const int m = bm * BM + wm * (16 * WM) + i * 16 + frow;
+    const int m = cbm * BM + wm * (16 * WM) + i * 16 + frow;
     if (m >= p.M) continue;
     const float* rv = nullptr;
     if (p.rowvec) rv = p.rowvec + (long long)(m / hw) * p.ldrv;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int n = bn * BN + wn * (16 * WN) + j * 16 + fg * 4;
+      const int n = cbn * BN + wn * (16 * WN) + j * 16 + fg * 4;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (n + 3 < p.N) {
@@ -377,6 +214,459 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p) {
         }
       }
     }
+  }
+    }
+}
+
+// PW: pointwise (1x1, stride 1, no pad, no upsample): the A row of output pixel m is input
+// pixel m -- no window arithmetic at all.
+// Persistent over tiles: workgroup b walks tiles s(b), s(b)+G, s(b)+2G ... (s = XCD-aware
+// remap of the block id, G = gridDim.x).  The global loads of the NEXT tile's first two
+// K-tiles are issued before the current tile's epilogue, so workgroups stream continuously
+// instead of loading / storing in lock-step bursts (short-K layers are memory-bound).
+template <typename T, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, const int ntiles) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
+  constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
+  __shared__ u32x4 lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware order (bijective for any grid size): blocks b and b+8 share an XCD and
+  //      get neighbouring tiles (same activation rows -> same L2) ----
+  const int nbn = (p.N + BN - 1) / BN;
+  const int G = gridDim.x;
+  int tile;
+  {
+    const int L = blockIdx.x;
+    const int qd = G >> 3, rr = G & 7, xcd = L & 7, idx = L >> 3;
+    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
+  }
+  const int z = blockIdx.z;
+  const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
+
+  const T* a0 = reinterpret_cast<const T*>(p.a0) + (i1 * p.sa1 + i2 * p.sa2);
+  const T* a1 = reinterpret_cast<const T*>(p.a1);
+  const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
+  const long long ooff = i1 * p.so1 + i2 * p.so2;
+
+  // ---- K range of this block (split-K over gridDim.y) ----
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * kt_per;
+  const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
+
+  // ---- loader state (re-initialised per tile by setup_tile) ----
+  // FAST mode (every SD-1.5 layer): a K-tile lies inside ONE tap of ONE source, so the tap,
+  // the source and the channel offset are wave-uniform scalars; each lane keeps, per A row,
+  // the pixel index of the window centre and a bitmask of the taps that fall inside the
+  // image, and per B row a constant byte offset.  A K-tile of loads then costs ~3 VALU
+  // instructions per A row and none per B row.  GENERIC mode (channel counts below one
+  // K-tile, nearest-x2 upsample, ragged concat) derives tap / source per lane.
+  constexpr int SZ = (int)sizeof(T);
+  const int kc = tid & 7;
+  const int r0 = tid >> 3;  // rows r0 + 32*i
+  const int hw = p.hout * p.wout;
+  const int ctot = p.c0 + p.c1;
+  const int hv = p.upsample ? 2 * p.hin : p.hin;
+  const int wv = p.upsample ? 2 * p.win : p.win;
+  const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !p.upsample;
+  const rsrc_t rs0 = make_rsrc(a0);
+  const rsrc_t rs1 = make_rsrc(p.c1 > 0 ? (const void*)a1 : (const void*)a0);
+  const rsrc_t rsw = make_rsrc(w);
+  int bm = 0, bn = 0;
+  int row_a[A_CH], row_b[A_CH], row_c[A_CH];  // FAST: (centre pixel, tap mask, -); GENERIC: (iy0, ix0, pix0) / PW (m,-,-)
+  unsigned offb[B_CH];                        // byte offset of (weight row, chunk kc) or kInvalid
+  int k = 0, c = 0, dy = 0, dx = 0;           // GENERIC: per-lane k-state
+  int ku = 0, cu = 0, dyu = 0, dxu = 0;       // FAST: wave-uniform k-state (tile start)
+
+  auto setup_tile = [&](int t) __attribute__((always_inline)) {
+    bm = t / nbn;
+    bn = t - bm * nbn;
+    if (PW) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int m = bm * BM + r0 + 32 * i;
+        row_a[i] = (m < p.M) ? m : -1;
+        row_b[i] = (m < p.M) ? 1 : 0;
+        row_c[i] = 0;
+      }
+    } else {
+      // first row by division, the following rows (+32 each) by carry propagation
+      int m = bm * BM + r0;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / p.wout;
+      int ox = rem - oy * p.wout;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        if (fast) {
+          // centre pixel of the window and the validity bit of every tap
+          row_a[i] = b * p.hin * p.win + (oy * p.stride) * p.win + ox * p.stride;
+          int mask = 0;
+          if (m < p.M) {
+            for (int ty = 0; ty < p.kh; ++ty)
+              for (int tx = 0; tx < p.kw; ++tx)
+                if ((unsigned)(iy0 + ty) < (unsigned)hv && (unsigned)(ix0 + tx) < (unsigned)wv) mask |= 1 << (ty * p.kw + tx);
+          }
+          row_b[i] = mask;
+          row_c[i] = 0;
+        } else if (m < p.M) {
+          row_a[i] = iy0;
+          row_b[i] = ix0;
+          row_c[i] = b * p.hin * p.win;
+        } else {
+          row_a[i] = row_b[i] = -(1 << 28);
+          row_c[i] = 0;
+        }
+        m += 32;
+        ox += 32;
+        while (ox >= p.wout) { ox -= p.wout; ++oy; }
+        while (oy >= p.hout) { oy -= p.hout; ++b; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int n = bn * BN + r0 + 32 * i;
+      offb[i] = (n < p.N) ? (unsigned)(n * p.ldw * SZ + kc * 16) : kInvalid;
+    }
+    k = kt0 * BK + kc * EPC;
+    const int tap = k / ctot;
+    c = k - tap * ctot;
+    dy = tap / p.kw;
+    dx = tap - dy * p.kw;
+    ku = kt0 * BK;
+    const int tapu = ku / ctot;
+    cu = ku - tapu * ctot;
+    dyu = tapu / p.kw;
+    dxu = tapu - dyu * p.kw;
+  };
+
+  // two register staging sets: while tile t is being multiplied out of LDS, tiles t+1 and
+  // t+2 are in flight from global memory (two K-tiles of loads outstanding per workgroup)
+  u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];
+
+  auto load_tile = [&](u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
+    if (fast) {
+      // ---- wave-uniform tap / source / channel offset ----
+      const bool s0 = cu < p.c0;
+      const rsrc_t rs = s0 ? rs0 : rs1;
+      const int ldsz = (s0 ? p.lda0 : p.lda1) * SZ;
+      const unsigned soff = (unsigned)((s0 ? cu : cu - p.c0) * SZ);
+      const int tapbit = dyu * p.kw + dxu;
+      const int pixoff = PW ? 0 : (dyu - p.pad) * p.win + (dxu - p.pad);
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const unsigned off = (unsigned)((row_a[i] + pixoff) * ldsz + kc * 16);
+        const bool ok = PW ? (row_b[i] != 0) : (((row_b[i] >> tapbit) & 1) != 0);
+        ra[i] = buf_load(rs, ok ? off : kInvalid, soff);
+      }
+      const unsigned soffw = (unsigned)(ku * SZ);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = buf_load(rsw, offb[i], soffw);
+      ku += BK;
+      cu += BK;
+      if (cu >= ctot) {
+        cu -= ctot;
+        if (++dxu == p.kw) { dxu = 0; ++dyu; }
+      }
+    } else {
+      // ---- per-lane tap / source (small channel counts, upsample, ragged concat) ----
+      const bool kvalid = k < p.K;
+      const bool s0 = c < p.c0;
+      const int ld = s0 ? p.lda0 : p.lda1;
+      const int cc = s0 ? c : c - p.c0;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        unsigned off;
+        bool inb;
+        if (PW) {
+          inb = kvalid && row_a[i] >= 0;
+          off = (unsigned)((row_a[i] * ld + cc) * SZ);
+        } else {
+          int iy = row_a[i] + dy, ix = row_b[i] + dx;
+          inb = kvalid && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
+          if (p.upsample) { iy >>= 1; ix >>= 1; }
+          off = (unsigned)(((row_c[i] + iy * p.win + ix) * ld + cc) * SZ);
+        }
+        u32x4 v = buf_load(rs0, (inb && s0) ? off : kInvalid, 0u);
+        if (p.c1 > 0) v |= buf_load(rs1, (inb && !s0) ? off : kInvalid, 0u);
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) rb[i] = buf_load(rsw, kvalid ? offb[i] + (unsigned)((k - kc * EPC) * SZ) : kInvalid, 0u);
+      k += BK;
+      c += BK;
+      while (c >= ctot) {
+        c -= ctot;
+        if (++dx == p.kw) { dx = 0; ++dy; }
+      }
+    }
+  };
+  auto store_tile = [&](int stage, const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH]) __attribute__((always_inline)) {
+    u32x4* la = lds + stage * STAGE;
+    u32x4* lb = la + BM * 8;
+    const int sw = kc ^ (r0 & 7);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) la[(r0 + 32 * i) * 8 + sw] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) lb[(r0 + 32 * i) * 8 + sw] = rb[i];
+  };
+
+  f32x4 acc[WM][WN];
+  const int frow = lane & 15, fg = lane >> 4;
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const u32x4* la = lds + stage * STAGE;
+    const u32x4* lb = la + BM * 8;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = kk * 4 + fg;
+      u32x4 xa[WM], wb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * (16 * WM) + i * 16 + frow;
+        xa[i] = la[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int row = wn * (16 * WN) + j * 16 + frow;
+        wb[j] = lb[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) Mma<T>::run(wb[j], xa[i], acc[i][j]);
+    }
+  };
+
+  setup_tile(tile);
+  if (nk > 0) load_tile(ra0, rb0);
+  if (nk > 1) load_tile(ra1, rb1);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nk > 0) store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even tile kt: LDS stage 0; set 0 is free -> prefetch tile kt+2; set 1 (tile kt+1) -> stage 1
+      if (kt + 2 < nk) load_tile(ra0, rb0);
+      compute(0);
+      if (kt + 1 < nk) store_tile(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd tile kt+1: LDS stage 1; set 1 is free -> prefetch tile kt+3; set 0 (tile kt+2) -> stage 0
+      if (kt + 3 < nk) load_tile(ra1, rb1);
+      compute(1);
+      if (kt + 2 < nk) store_tile(0, ra0, rb0);
+      __syncthreads();
+    }
+
+    // ---- next tile: its first two K-tiles go in flight now, under this tile's epilogue ----
+    const int cbm = bm, cbn = bn;
+    const int next = tile + G;
+    const bool has_next = next < ntiles;
+    if (has_next) {
+      setup_tile(next);
+      if (nk > 0) load_tile(ra0, rb0);
+      if (nk > 1) load_tile(ra1, rb1);
+    }
+
+    gemm_epilogue<T, WM, WN>(p, acc, lds, cbm, cbn, ooff);
+    if (!has_next) break;
+    tile = next;
+    __syncthreads();   // LDS reads of the staged epilogue are done before the next tile's first store
+  }
+}
+
+// ---- LDS-DMA variant (FAST layers: a K-tile lies inside one tap of one source) -------------
+// Operand tiles go global -> LDS directly (buffer_load ... lds): no staging VGPRs and no
+// ds_write pass (register staging costs ~9 KB of ds_write_b128 per wave per K-tile at only
+// ~79 B/clk/CU, which alone exceeds the MFMA time of the tile).  The LDS image is lane-linear
+// per wave instruction (64 lanes x 16 B = 8 rows x 128 B), so the XOR swizzle is applied on
+// the SOURCE side: the lane that lands in slot s of row r fetches logical chunk s ^ (r & 7);
+// the fragment reads apply the same XOR.  Out-of-range lanes (M / N edge, halo) use an offset
+// beyond num_records and land as zeros.  Two LDS stages: the DMA of tile t+1 is in flight
+// during the MFMAs of tile t; one barrier per K-tile.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <typename T, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams p, const int ntiles) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
+  constexpr int SZ = (int)sizeof(T);
+  __shared__ u32x4 lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbn = (p.N + BN - 1) / BN;
+  const int G = gridDim.x;
+  int tile;
+  {
+    const int L = blockIdx.x;
+    const int qd = G >> 3, rr = G & 7, xcd = L & 7, idx = L >> 3;
+    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
+  }
+  const int z = blockIdx.z;
+  const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
+  const T* a0 = reinterpret_cast<const T*>(p.a0) + (i1 * p.sa1 + i2 * p.sa2);
+  const T* a1 = reinterpret_cast<const T*>(p.a1);
+  const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
+  const long long ooff = i1 * p.so1 + i2 * p.so2;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * kt_per;
+  const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
+
+  const int r0 = tid >> 3;                        // tile row r0 + 32*i lands in LDS row r0 + 32*i
+  const int kcs = (tid & 7) ^ (r0 & 7);           // logical 16-byte chunk fetched by this lane
+  const int hw = p.hout * p.wout;
+  const int ctot = p.c0 + p.c1;
+  const rsrc_t rs0 = make_rsrc(a0);
+  const rsrc_t rs1 = make_rsrc(p.c1 > 0 ? (const void*)a1 : (const void*)a0);
+  const rsrc_t rsw = make_rsrc(w);
+  int bm = 0, bn = 0;
+  int pix[A_CH], msk[A_CH];
+  unsigned offb[B_CH];
+  int ku = 0, cu = 0, dyu = 0, dxu = 0;
+
+  auto setup_tile = [&](int t) __attribute__((always_inline)) {
+    bm = t / nbn;
+    bn = t - bm * nbn;
+    if (PW) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int m = bm * BM + r0 + 32 * i;
+        pix[i] = m;
+        msk[i] = (m < p.M) ? 1 : 0;
+      }
+    } else {
+      int m = bm * BM + r0;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / p.wout;
+      int ox = rem - oy * p.wout;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        pix[i] = b * p.hin * p.win + (oy * p.stride) * p.win + ox * p.stride;
+        int mask = 0;
+        if (m < p.M) {
+          for (int ty = 0; ty < p.kh; ++ty)
+            for (int tx = 0; tx < p.kw; ++tx)
+              if ((unsigned)(iy0 + ty) < (unsigned)p.hin && (unsigned)(ix0 + tx) < (unsigned)p.win) mask |= 1 << (ty * p.kw + tx);
+        }
+        msk[i] = mask;
+        m += 32;
+        ox += 32;
+        while (ox >= p.wout) { ox -= p.wout; ++oy; }
+        while (oy >= p.hout) { oy -= p.hout; ++b; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int n = bn * BN + r0 + 32 * i;
+      offb[i] = (n < p.N) ? (unsigned)(n * p.ldw * SZ + kcs * 16) : kInvalid;
+    }
+    ku = kt0 * BK;
+    const int tapu = ku / ctot;
+    cu = ku - tapu * ctot;
+    dyu = tapu / p.kw;
+    dxu = tapu - dyu * p.kw;
+  };
+
+  auto dma_tile = [&](int stage) __attribute__((always_inline)) {
+    const bool s0 = cu < p.c0;
+    const rsrc_t rs = s0 ? rs0 : rs1;
+    const int ldsz = (s0 ? p.lda0 : p.lda1) * SZ;
+    const int soff = (s0 ? cu : cu - p.c0) * SZ;
+    const int tapbit = dyu * p.kw + dxu;
+    const int pixoff = PW ? 0 : (dyu - p.pad) * p.win + (dxu - p.pad);
+    u32x4* la = lds + stage * STAGE;
+    u32x4* lb = la + BM * 8;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned off = (unsigned)((pix[i] + pixoff) * ldsz + kcs * 16);
+      const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (32 * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
+                                               soff, 0, 0);
+    }
+    const int soffw = ku * SZ;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (32 * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
+    ku += BK;
+    cu += BK;
+    if (cu >= ctot) {
+      cu -= ctot;
+      if (++dxu == p.kw) { dxu = 0; ++dyu; }
+    }
+  };
+
+  f32x4 acc[WM][WN];
+  const int frow = lane & 15, fg = lane >> 4;
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const u32x4* la = lds + stage * STAGE;
+    const u32x4* lb = la + BM * 8;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = kk * 4 + fg;
+      u32x4 xa[WM], wb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * (16 * WM) + i * 16 + frow;
+        xa[i] = la[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int row = wn * (16 * WN) + j * 16 + frow;
+        wb[j] = lb[row * 8 + (chunk ^ (row & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) Mma<T>::run(wb[j], xa[i], acc[i][j]);
+    }
+  };
+
+  setup_tile(tile);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nk > 0) dma_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
+      __syncthreads();                                     // ... everyone's has; stage (kt+1)&1 is free again
+      if (kt + 1 < nk) dma_tile((kt + 1) & 1);
+      compute(kt & 1);
+    }
+    __syncthreads();   // every wave is done with the K-loop's LDS stages before the epilogue reuses them
+    const int cbm = bm, cbn = bn;
+    const int next = tile + G;
+    const bool has_next = next < ntiles;
+    if (has_next) setup_tile(next);
+    gemm_epilogue<T, WM, WN>(p, acc, lds, cbm, cbn, ooff);
+    if (!has_next) break;
+    tile = next;
+    __syncthreads();   // staged epilogue reads are done before the next tile's first DMA
   }
 }
 
@@ -425,10 +715,24 @@ template <typename T, int WM, int WN>
 int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-  dim3 grid(tiles, ksplit, p.nb1 * p.nb2);
+  // persistent grid: as many workgroups as the chip keeps resident (256 CUs x blocks/CU by LDS / VGPR budget)
+  constexpr int kResident = 256 * ((BM + BN) * 256 > 48 * 1024 ? 2 : 4);
+  const int zy = ksplit * p.nb1 * p.nb2;
+  int gx = tiles;
+  if ((long long)tiles * zy > kResident) gx = max(1, min(tiles, kResident / zy));
+  dim3 grid(gx, ksplit, p.nb1 * p.nb2);
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
-  if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p);
+  constexpr int BK = 128 / (int)sizeof(T);
+  const int ctot = p.c0 + p.c1;
+  static const bool dma_off = getenv("SASPA_GEMM_DMA") && atoi(getenv("SASPA_GEMM_DMA")) == 0;   // A/B knob
+  const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !p.upsample && !dma_off;
+  if (fast) {
+    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
+    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
+  } else {
+    if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
+    else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
+  }
   SASPA_CHECK_LAUNCH();
   if (ksplit > 1) {
     long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;
@@ -485,6 +789,15 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     if ((p.hout - 1) * p.stride - p.pad >= hv || (p.wout - 1) * p.stride - p.pad >= wv) return SASPA_ERANGE;
   }
   if ((long long)p.batch * p.hin * p.win >= (1ll << 31)) return SASPA_ERANGE;
+  {
+    // buffer loads address every operand with 32-bit byte offsets below 2 GiB
+    const long long esz = p.dtype == SASPA_BF16 ? 2 : 4;
+    const long long a0b = (long long)p.batch * p.hin * p.win * p.lda0 * esz;
+    const long long a1b = p.c1 > 0 ? (long long)p.batch * p.hin * p.win * p.lda1 * esz : 0;
+    const long long wb = (long long)p.N * p.ldw * esz;
+    if (a0b >= (1ll << 31) || a1b >= (1ll << 31) || wb >= (1ll << 31)) return SASPA_ERANGE;
+    if (p.kh * p.kw > 31) return SASPA_ERANGE;
+  }
   if (p.ksplit < 0 || p.ksplit > 64) return SASPA_ERANGE;
   if (p.act == SASPA_ACT_GEGLU) {
     // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
 
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const u32x4 ones4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // bf16 1.0 x8
 
   // ---- Q fragments (B operand), resident for the whole kernel ----
   u32x4 qf[KS];
@@ -60,63 +59,77 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
   }
 
-  // ---- staging bookkeeping (loop invariant per thread) ----
-  int k_key[NCH_K], k_ch[NCH_K];
+  // ---- staging: bounds-checked buffer loads (an offset >= num_records returns zeros), per-lane
+  //      offsets fixed for the whole kernel, the tile advance in a scalar offset ----
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kp), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned kInv = 0x80000000u;
+  unsigned koff[NCH_K], voff[NCH_V];
+  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_d[NCH_V], v_kc[NCH_V];
 #pragma unroll
   for (int i = 0; i < NCH_K; ++i) {
     const int q = tid + 256 * i;
-    k_key[i] = q / KCH;
-    k_ch[i] = q - k_key[i] * KCH;
+    const int key = q / KCH, ch = q - key * KCH;
+    k_key[i] = key;
+    k_lds[i] = (q < 64 * KCH) ? (key * KSLOTS + ch) * 16 : -1;
+    koff[i] = (q < 64 * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;   // pad chunks read as zeros
+  }
+#pragma unroll
+  for (int i = 0; i < NCH_V; ++i) {
+    const int q = tid + 256 * i;
+    const int d = q >> 3, kc = q & 7;
+    v_d[i] = d;
+    v_kc[i] = kc;
+    v_lds[i] = (q < DV * 8 && d < D) ? d * VROW + kc * 16 : -1;     // rows >= D are written once, below
+    voff[i] = (q < DV * 8 && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
+  }
+  // rows D .. DV-1 of the V^T tile never change: ones (denominator row, when ONES) / zeros
+  for (int q = tid; q < DV * 8; q += 256) {
+    const int d = q >> 3, kc = q & 7;
+    if (d >= D) {
+      const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
+      u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
+      dst[0] = u32x2{fill, fill};
+      dst[1] = u32x2{fill, fill};
+    }
   }
   u32x4 kreg[NCH_K], vreg[NCH_V];
 
   auto load_tile = [&](int key0) __attribute__((always_inline)) {
+    const bool tail = key0 + 64 > p.nk;                  // wave-uniform
+    const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
 #pragma unroll
     for (int i = 0; i < NCH_K; ++i) {
-      const int q = tid + 256 * i;
-      u32x4 v = zero4;
-      if (q < 64 * KCH && k_ch[i] < D8 && key0 + k_key[i] < p.nk)
-        v = *reinterpret_cast<const u32x4*>(Kp + (long long)(key0 + k_key[i]) * p.ldk + k_ch[i] * 8);
-      kreg[i] = v;
+      unsigned o = koff[i];
+      if (tail && key0 + k_key[i] >= p.nk) o = kInv;
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)o, (int)sk, 0));
     }
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
-      const int q = tid + 256 * i;
-      const int d = q >> 3, kk = key0 + (q & 7) * 8;
-      u32x4 v = zero4;
-      if (q < DV * 8) {
-        if (d < D) {
-          if (kk < p.nk) v = *reinterpret_cast<const u32x4*>(VT + (long long)d * p.ldvt + kk);
-        } else if (ONES && d == D) {
-          v = ones4;
-        }
-      }
-      vreg[i] = v;
+      unsigned o = voff[i];
+      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
     }
   };
   auto store_tile = [&](int key0) __attribute__((always_inline)) {
     const bool tail = key0 + 64 > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
 #pragma unroll
-    for (int i = 0; i < NCH_K; ++i) {
-      const int q = tid + 256 * i;
-      if (q < 64 * KCH) *reinterpret_cast<u32x4*>(ksm + (k_key[i] * KSLOTS + k_ch[i]) * 16) = kreg[i];
-    }
+    for (int i = 0; i < NCH_K; ++i)
+      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
-      const int q = tid + 256 * i;
-      if (q < DV * 8) {
-        const int d = q >> 3, kc = q & 7;
+      if (v_lds[i] >= 0) {
         u32x4 v = vreg[i];
-        if (tail && d < D) {
+        if (tail) {
           // zero the keys >= nk (pad columns of vt are not initialised by the producer)
-          const int nvalid = p.nk - (key0 + kc * 8);
+          const int nvalid = p.nk - (key0 + v_kc[i] * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
             v[e] &= keep;
           }
         }
-        u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
+        u32x2* dst = reinterpret_cast<u32x2*>(vsm + v_lds[i]);
         dst[0] = u32x2{v.x, v.y};
         dst[1] = u32x2{v.z, v.w};
       }
@@ -289,6 +302,7 @@ extern "C" int saspa_flash_attn_bf16(const SaspaAttnParams* pp, void* stream) {
   if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.vt) || !aligned16(p.o)) return SASPA_EALIGN;
   if (p.ldvt < ((p.nk + 7) / 8) * 8) return SASPA_ERANGE;
   if (p.ldq < p.heads * p.D || p.ldk < p.heads * p.D || p.ldo < p.heads * p.D) return SASPA_ERANGE;
+  if ((long long)p.nk * p.ldk * 2 >= (1ll << 31) || (long long)p.D * p.ldvt * 2 >= (1ll << 31)) return SASPA_ERANGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int D = p.D;
   if (D <= 16) return launch_attn<1, 1>(p, s);

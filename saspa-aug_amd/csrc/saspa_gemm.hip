@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
         unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + ch * 8), a);
         unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + HB + ch * 8), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+        for (int e = 0; e < 8; ++e) a[e] = fast_gelu_mul(a[e], g[e]);
         *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + f) = pack8(a);
       }
     }

@@ -499,15 +499,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
 // during the MFMAs of tile t; one barrier per K-tile.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <typename T, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams p, const int ntiles) {
+template <typename T, int WM, int WN, bool PW, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(const SaspaGemmParams p, const int ntiles) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
   constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
   constexpr int SZ = (int)sizeof(T);
-  __shared__ u32x4 lds[2 * STAGE];
+  __shared__ u32x4 lds[NSTAGE * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams 
   const rsrc_t rs1 = make_rsrc(p.c1 > 0 ? (const void*)a1 : (const void*)a0);
   const rsrc_t rsw = make_rsrc(w);
   int bm = 0, bn = 0;
-  int pix[A_CH], msk[A_CH];
+  int pix[A_CH], msk[A_CH], upc[A_CH];
+  const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
   unsigned offb[B_CH];
   int ku = 0, cu = 0, dyu = 0, dxu = 0;
 
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams 
         const int m = bm * BM + r0 + 32 * i;
         pix[i] = m;
         msk[i] = (m < p.M) ? 1 : 0;
+        upc[i] = 0;
       }
     } else {
       int m = bm * BM + r0;
@@ -565,12 +567,19 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams 
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        pix[i] = b * p.hin * p.win + (oy * p.stride) * p.win + ox * p.stride;
+        if (p.upsample) {
+          // nearest x2: the window walks the virtual 2H x 2W grid; keep its top-left corner
+          // (packed y | x) and resolve the source pixel ((iy0+dy)>>1, (ix0+dx)>>1) per tap
+          pix[i] = b * p.hin * p.win;
+          upc[i] = ((iy0 + 1) << 16) | (ix0 + 1);     // +1 keeps both halves non-negative (pad <= 1)
+        } else {
+          pix[i] = b * p.hin * p.win + (oy * p.stride) * p.win + ox * p.stride;
+        }
         int mask = 0;
         if (m < p.M) {
           for (int ty = 0; ty < p.kh; ++ty)
             for (int tx = 0; tx < p.kw; ++tx)
-              if ((unsigned)(iy0 + ty) < (unsigned)p.hin && (unsigned)(ix0 + tx) < (unsigned)p.win) mask |= 1 << (ty * p.kw + tx);
+              if ((unsigned)(iy0 + ty) < (unsigned)hv && (unsigned)(ix0 + tx) < (unsigned)wv) mask |= 1 << (ty * p.kw + tx);
         }
         msk[i] = mask;
         m += 32;
@@ -602,7 +611,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams 
     u32x4* lb = la + BM * 8;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const unsigned off = (unsigned)((pix[i] + pixoff) * ldsz + kcs * 16);
+      int px = pix[i] + pixoff;
+      if (!PW && p.upsample) {
+        const int iy = ((upc[i] >> 16) - 1 + dyu) >> 1, ix = ((upc[i] & 0xffff) - 1 + dxu) >> 1;
+        px = pix[i] + iy * p.win + ix;
+      }
+      const unsigned off = (unsigned)(px * ldsz + kcs * 16);
       const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (32 * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
                                                soff, 0, 0);
@@ -651,12 +665,23 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const SaspaGemmParams 
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nk > 0) dma_tile(0);
+    // NSTAGE-deep ring: tiles kt+1 .. kt+NSTAGE-1 are in flight while tile kt is multiplied.
+    // Counted vmcnt + raw s_barrier (a __syncthreads() would drain every DMA).
+    constexpr int GROUP = A_CH + B_CH;                 // DMA instructions per K-tile per wave
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+      if (st < nk) dma_tile(st);
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
-      __syncthreads();                                     // ... everyone's has; stage (kt+1)&1 is free again
-      if (kt + 1 < nk) dma_tile((kt + 1) & 1);
-      compute(kt & 1);
+      // tile kt has landed once at most (NSTAGE-2) younger groups are outstanding
+      if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * GROUP) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                    // everyone's share landed; stage of tile kt-1 is free
+      asm volatile("" ::: "memory");
+      if (kt + NSTAGE - 1 < nk) dma_tile((kt + NSTAGE - 1) % NSTAGE);
+      compute(kt % NSTAGE);
     }
     __syncthreads();   // every wave is done with the K-loop's LDS stages before the epilogue reuses them
     const int cbm = bm, cbn = bn;
@@ -725,10 +750,21 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BK = 128 / (int)sizeof(T);
   const int ctot = p.c0 + p.c1;
   static const bool dma_off = getenv("SASPA_GEMM_DMA") && atoi(getenv("SASPA_GEMM_DMA")) == 0;   // A/B knob
-  const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !p.upsample && !dma_off;
+  const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
+                    (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
   if (fast) {
-    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
-    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
+    // few tiles (<= ~1 workgroup per CU): spend the idle LDS on a 4-deep DMA ring (latency-bound
+    // K loops); otherwise 2 stages and 2 workgroups per CU
+    static const int force_st = getenv("SASPA_GEMM_STAGES") ? atoi(getenv("SASPA_GEMM_STAGES")) : 0;
+    constexpr bool can4 = (BM + BN) * 128 * 4 <= 160 * 1024;
+    const bool deep = can4 && (force_st ? force_st == 4 : (long long)tiles * zy <= 320);
+    if (deep) {
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
+    } else {
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true, 2>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false, 2>), grid, dim3(256), 0, s, p, tiles);
+    }
   } else {
     if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
     else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
@@ -749,11 +785,16 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
   const bool n160 = (p.N % 160) == 0;
   if (p.act == SASPA_ACT_GEGLU) return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
+  static const int force_tile = getenv("SASPA_GEMM_TILE") ? atoi(getenv("SASPA_GEMM_TILE")) : 0;   // tuning knob
+  if (force_tile == 45) return launch<T, 4, 5>(p, s, ksplit);
+  if (force_tile == 44) return launch<T, 4, 4>(p, s, ksplit);
+  if (force_tile == 25) return launch<T, 2, 5>(p, s, ksplit);
+  if (force_tile == 24) return launch<T, 2, 4>(p, s, ksplit);
+  if (force_tile == 22) return launch<T, 2, 2>(p, s, ksplit);
+  if (force_tile == 41) return launch<T, 4, 1>(p, s, ksplit);
   if (p.N <= 32) return launch<T, 4, 1>(p, s, 1);
   const int bn = n160 ? 160 : 128;
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
-  static const int force_small = getenv("SASPA_GEMM_SMALLK") ? atoi(getenv("SASPA_GEMM_SMALLK")) : 0;   // experiment knob
-  if (force_small && p.K <= force_small) return launch<T, 2, 2>(p, s, ksplit);
   if (tiles >= 160 && p.N > 64) return n160 ? launch<T, 4, 5>(p, s, ksplit) : launch<T, 4, 4>(p, s, ksplit);
   return launch<T, 2, 2>(p, s, ksplit);
 }

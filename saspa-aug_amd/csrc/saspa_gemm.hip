@@ -69,14 +69,14 @@ template <> struct Mma<float> {
 // residual read) are whole 16-byte chunks of contiguous output rows; GEGLU pairs the value /
 // gate halves there.  fp32 parity mode / odd N: direct per-lane path.
 // The caller guarantees every wave has finished reading the K-loop's LDS stages.
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int NWM = 2, int NWN = 2>
 __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&acc)[WM][WN], u32x4* lds, const int cbm,
                                               const int cbn, const long long ooff) {
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int frow = lane & 15, fg = lane >> 4;
   const int hw = p.hout * p.wout;
   T* out = reinterpret_cast<T*>(p.out) + ooff;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
     __syncthreads();
     if (!geglu) {
       constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
-      for (int q = tid; q < BM * CPR; q += 256) {
+      for (int q = tid; q < BM * CPR; q += NT) {
         const int row = q / CPR, ch = q - row * CPR;
         const int m = cbm * BM + row, n = cbn * BN + ch * 8;
         if (m >= p.M || n >= p.N) continue;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
     } else {
       // tile columns [0, BN/2) are values, [BN/2, BN) the matching gates (weights packed so)
       constexpr int HB = BN / 2, CPR = HB / 8;
-      for (int q = tid; q < BM * CPR; q += 256) {
+      for (int q = tid; q < BM * CPR; q += NT) {
         const int row = q / CPR, ch = q - row * CPR;
         const int m = cbm * BM + row, f = cbn * HB + ch * 8;
         if (m >= p.M) continue;
@@ -499,12 +499,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
 // during the MFMAs of tile t; one barrier per K-tile.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <typename T, int WM, int WN, bool PW, int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(const SaspaGemmParams p, const int ntiles) {
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE>
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 : 2) void gemm_dma_kernel(const SaspaGemmParams p,
+                                                                                                      const int ntiles) {
+  constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
+  constexpr int RPI = NT / 8;                         // tile rows covered by one DMA instruction of the whole workgroup
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int A_CH = (BM + RPI - 1) / RPI, B_CH = (BN + RPI - 1) / RPI;
+  static_assert(NSTAGE == 2 || (BM % RPI == 0 && BN % RPI == 0), "counted vmcnt needs whole DMA groups per wave");
   constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
   constexpr int SZ = (int)sizeof(T);
   __shared__ u32x4 lds[NSTAGE * STAGE];
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   const int nbn = (p.N + BN - 1) / BN;
   const int G = gridDim.x;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
   const int kt0 = blockIdx.y * kt_per;
   const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
 
-  const int r0 = tid >> 3;                        // tile row r0 + 32*i lands in LDS row r0 + 32*i
+  const int r0 = tid >> 3;                        // tile row r0 + RPI*i lands in LDS row r0 + RPI*i
   const int kcs = (tid & 7) ^ (r0 & 7);           // logical 16-byte chunk fetched by this lane
   const int hw = p.hout * p.wout;
   const int ctot = p.c0 + p.c1;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
     if (PW) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const int m = bm * BM + r0 + 32 * i;
+        const int m = bm * BM + r0 + RPI * i;
         pix[i] = m;
         msk[i] = (m < p.M) ? 1 : 0;
         upc[i] = 0;
@@ -582,16 +585,16 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
               if ((unsigned)(iy0 + ty) < (unsigned)hv && (unsigned)(ix0 + tx) < (unsigned)wv) mask |= 1 << (ty * p.kw + tx);
         }
         msk[i] = mask;
-        m += 32;
-        ox += 32;
+        m += RPI;
+        ox += RPI;
         while (ox >= p.wout) { ox -= p.wout; ++oy; }
         while (oy >= p.hout) { oy -= p.hout; ++b; }
       }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const int n = bn * BN + r0 + 32 * i;
-      offb[i] = (n < p.N) ? (unsigned)(n * p.ldw * SZ + kcs * 16) : kInvalid;
+      const int n = bn * BN + r0 + RPI * i;
+      offb[i] = (n < p.N && r0 + RPI * i < BN) ? (unsigned)(n * p.ldw * SZ + kcs * 16) : kInvalid;
     }
     ku = kt0 * BK;
     const int tapu = ku / ctot;
@@ -618,13 +621,15 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
       }
       const unsigned off = (unsigned)(px * ldsz + kcs * 16);
       const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (32 * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
-                                               soff, 0, 0);
+      if (RPI * i + 8 * wave < BM)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (RPI * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
+                                                 soff, 0, 0);
     }
     const int soffw = ku * SZ;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (32 * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
+      if (RPI * i + 8 * wave < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (RPI * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
     ku += BK;
     cu += BK;
     if (cu >= ctot) {
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_dma_kernel(cons
     const int next = tile + G;
     const bool has_next = next < ntiles;
     if (has_next) setup_tile(next);
-    gemm_epilogue<T, WM, WN>(p, acc, lds, cbm, cbn, ooff);
+    gemm_epilogue<T, WM, WN, NWM, NWN>(p, acc, lds, cbm, cbn, ooff);
     if (!has_next) break;
     tile = next;
     __syncthreads();   // staged epilogue reads are done before the next tile's first DMA
@@ -736,12 +741,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SaspaGemmParam
   }
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int NWM = 2, int NWN = 2>
 int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   // persistent grid: as many workgroups as the chip keeps resident (256 CUs x blocks/CU by LDS / VGPR budget)
-  constexpr int kResident = 256 * ((BM + BN) * 256 > 48 * 1024 ? 2 : 4);
+  constexpr int kResident = 256 * (NT > 256 ? 1 : ((BM + BN) * 256 > 48 * 1024 ? 2 : 4));
   const int zy = ksplit * p.nb1 * p.nb2;
   int gx = tiles;
   if ((long long)tiles * zy > kResident) gx = max(1, min(tiles, kResident / zy));
@@ -752,18 +757,23 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   static const bool dma_off = getenv("SASPA_GEMM_DMA") && atoi(getenv("SASPA_GEMM_DMA")) == 0;   // A/B knob
   const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
                     (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
-  if (fast) {
+  if constexpr (NT != 256) {
+    // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
+    if (!fast) return SASPA_ERANGE;
+    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 2>), grid, dim3(NT), 0, s, p, tiles);
+    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 2>), grid, dim3(NT), 0, s, p, tiles);
+  } else if (fast) {
     // few tiles (<= ~1 workgroup per CU): spend the idle LDS on a 4-deep DMA ring (latency-bound
     // K loops); otherwise 2 stages and 2 workgroups per CU
     static const int force_st = getenv("SASPA_GEMM_STAGES") ? atoi(getenv("SASPA_GEMM_STAGES")) : 0;
     constexpr bool can4 = (BM + BN) * 128 * 4 <= 160 * 1024;
     const bool deep = can4 && (force_st ? force_st == 4 : (long long)tiles * zy <= 320);
     if (deep) {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
     } else {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, true, 2>), grid, dim3(256), 0, s, p, tiles);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, false, 2>), grid, dim3(256), 0, s, p, tiles);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles);
     }
   } else {
     if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
@@ -786,6 +796,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const bool n160 = (p.N % 160) == 0;
   if (p.act == SASPA_ACT_GEGLU) return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
   static const int force_tile = getenv("SASPA_GEMM_TILE") ? atoi(getenv("SASPA_GEMM_TILE")) : 0;   // tuning knob
+  if (force_tile == 845) return launch<T, 4, 5, 4, 2>(p, s, ksplit);   // 256x160, 8 waves
   if (force_tile == 45) return launch<T, 4, 5>(p, s, ksplit);
   if (force_tile == 44) return launch<T, 4, 4>(p, s, ksplit);
   if (force_tile == 25) return launch<T, 2, 5>(p, s, ksplit);

@@ -30,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" ".join(f"{r:7.1f}" for r in res))
 else:
     print("tile   " + " ".join(f"{m}x{n}x{k}"[:14].rjust(14) for m, n, k in shapes))
-    for tile in ("0", "45", "44", "25", "24", "22"):
+    for tile in ("0", "845"):
         env = dict(os.environ, SASPA_GEMM_TILE=tile)
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         print(f"{tile:5s}  " + " ".join(v.rjust(14) for v in out.split()))

@@ -501,13 +501,24 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE>
 __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 : 2) void gemm_dma_kernel(const SaspaGemmParams p,
-                                                                                                      const int ntiles) {
+                                                                                                      const int ntiles_abl) {
+  // diagnostic ablation (tools/gemm_ablate.py only; 0 in production): bits 28..30 of the tile count
+  const int ntiles = ntiles_abl & 0x0fffffff;
+#ifdef SASPA_GEMM_ABLATION
+  const int abl = (ntiles_abl >> 28) & 15;     // 1: no MFMA  2: no LDS reads / MFMA  4: no DMA  8: MFMA on stale registers (no LDS reads)
+#else
+  constexpr int abl = 0;                       // production build: the ablation branches fold away
+#endif
   constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
   constexpr int RPI = NT / 8;                         // tile rows covered by one DMA instruction of the whole workgroup
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int A_CH = (BM + RPI - 1) / RPI, B_CH = (BN + RPI - 1) / RPI;
-  static_assert(NSTAGE == 2 || (BM % RPI == 0 && BN % RPI == 0), "counted vmcnt needs whole DMA groups per wave");
+  static_assert(BM % RPI == 0 || NSTAGE == 2, "counted vmcnt: A rows must fill whole DMA instructions");
+  // B rows may end inside the last DMA instruction: waves whose 8-row slice lies beyond BN skip it,
+  // so the number of DMA instructions per K-tile is wave-dependent (G_LO for the low waves)
+  constexpr int B_FULL = BN / RPI;                    // B instructions every wave issues
+  constexpr bool B_RAGGED = (BN % RPI) != 0;
   constexpr int STAGE = (BM + BN) * 8;  // u32x4 per stage
   constexpr int SZ = (int)sizeof(T);
   __shared__ u32x4 lds[NSTAGE * STAGE];
@@ -604,6 +615,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
   };
 
   auto dma_tile = [&](int stage) __attribute__((always_inline)) {
+    if (abl & 4) return;
     const bool s0 = cu < p.c0;
     const rsrc_t rs = s0 ? rs0 : rs1;
     const int ldsz = (s0 ? p.lda0 : p.lda1) * SZ;
@@ -621,14 +633,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       }
       const unsigned off = (unsigned)(px * ldsz + kcs * 16);
       const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
-      if (RPI * i + 8 * wave < BM)
+      if (BM % RPI == 0 || RPI * i + 8 * wave < BM)   // compile-time true for whole groups: no branch around the DMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (RPI * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
                                                  soff, 0, 0);
     }
     const int soffw = ku * SZ;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      if (RPI * i + 8 * wave < BN)
+      if (RPI * (i + 1) <= BN || RPI * i + 8 * wave < BN)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (RPI * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
     ku += BK;
     cu += BK;
@@ -641,12 +653,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
   f32x4 acc[WM][WN];
   const int frow = lane & 15, fg = lane >> 4;
   auto compute = [&](int stage) __attribute__((always_inline)) {
+    if (abl & 2) return;
     const u32x4* la = lds + stage * STAGE;
     const u32x4* lb = la + BM * 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int chunk = kk * 4 + fg;
       u32x4 xa[WM], wb[WN];
+      if (abl & 8) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) xa[i] = u32x4{(unsigned)chunk, (unsigned)i, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wb[j] = u32x4{(unsigned)j, (unsigned)stage, 0x3f803f80u, 0x3f803f80u};
+      } else {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = wm * (16 * WM) + i * 16 + frow;
@@ -656,6 +675,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       for (int j = 0; j < WN; ++j) {
         const int row = wn * (16 * WN) + j * 16 + frow;
         wb[j] = lb[row * 8 + (chunk ^ (row & 7))];
+      }
+      }
+      if (abl & 1) {
+        // keep the fragment reads alive without issuing MFMAs
+#pragma unroll
+        for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(xa[i]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" ::"v"(wb[j]));
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -672,20 +700,27 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // NSTAGE-deep ring: tiles kt+1 .. kt+NSTAGE-1 are in flight while tile kt is multiplied.
     // Counted vmcnt + raw s_barrier (a __syncthreads() would drain every DMA).
-    constexpr int GROUP = A_CH + B_CH;                 // DMA instructions per K-tile per wave
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st)
       if (st < nk) dma_tile(st);
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed once at most (NSTAGE-2) younger groups are outstanding
       if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * GROUP) : "memory");
+        if (B_RAGGED && RPI * B_FULL + 8 * wave < BN) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (A_CH + B_FULL + 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (A_CH + B_FULL)) : "memory");
+        }
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                    // everyone's share landed; stage of tile kt-1 is free
       asm volatile("" ::: "memory");
       if (kt + NSTAGE - 1 < nk) dma_tile((kt + NSTAGE - 1) % NSTAGE);
+      // the DMA must be ISSUED before the MFMA block so that it flies under it: without this fence
+      // hipcc's scheduler sinks all but one buffer_load..lds below the MFMAs (measured: DMA time
+      // and compute time then add up instead of overlapping)
+      __builtin_amdgcn_sched_barrier(0);
       compute(kt % NSTAGE);
     }
     __syncthreads();   // every wave is done with the K-loop's LDS stages before the epilogue reuses them
@@ -755,13 +790,15 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BK = 128 / (int)sizeof(T);
   const int ctot = p.c0 + p.c1;
   static const bool dma_off = getenv("SASPA_GEMM_DMA") && atoi(getenv("SASPA_GEMM_DMA")) == 0;   // A/B knob
+  static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;       // diagnostics only
+  const int tiles_abl = tiles | (abl << 28);
   const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
                     (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
   if constexpr (NT != 256) {
     // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
     if (!fast) return SASPA_ERANGE;
-    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 2>), grid, dim3(NT), 0, s, p, tiles);
-    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 2>), grid, dim3(NT), 0, s, p, tiles);
+    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
+    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
   } else if (fast) {
     // few tiles (<= ~1 workgroup per CU): spend the idle LDS on a 4-deep DMA ring (latency-bound
     // K loops); otherwise 2 stages and 2 workgroups per CU
@@ -769,11 +806,11 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
     constexpr bool can4 = (BM + BN) * 128 * 4 <= 160 * 1024;
     const bool deep = can4 && (force_st ? force_st == 4 : (long long)tiles * zy <= 320);
     if (deep) {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
     } else {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles_abl);
     }
   } else {
     if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);

@@ -72,6 +72,8 @@ class StableDiffusionControlNetPipeline:
 
     def to(self, device, dtype=None):
         device = torch.device(device)
+        if self._state_dicts is None:
+            raise RuntimeError("this pipeline was already placed on a device; build a new one to change device / dtype")
         if device.type != "cuda":
             raise RuntimeError("saspa_aug_amd pipelines run on an MI355X only (no CPU path); got device %s" % device)
         if not torch.cuda.is_available():
@@ -89,6 +91,7 @@ class StableDiffusionControlNetPipeline:
         self.vae = models.VAEDecoder(sd["vae"], cf["vae"], device, cdt)
         self.text_encoder = models.CLIPText(sd["text"], cf["text"], device, cdt)
         self._neg_cache = {}
+        self._state_dicts = None      # the packed device copies are the weights now; free ~5.6 GB of host fp32
         return self
 
     def upcast_vae(self):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224

@@ -1,7 +1,7 @@
 // Fused flash attention (bf16, fp32 accumulate) for gfx950 and the row-softmax used
 // by the unfused (fp32 parity / VAE 512-wide head) path.  See include/saspa_hip.h.
 //
-// Formulation (per wave: 32 queries, per workgroup: 4 waves = 128 queries, KV tile = 64 keys):
+// Formulation (per wave: 32 queries, per workgroup: 4 waves = 128 queries, KV tile = 64 or 128 keys):
 //   S^T = K Q^T     v_mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers).
 //                   The accumulator then has the QUERY on the lane (column) and 16 of the
 //                   32 keys in registers, so the softmax max / sum are in-register plus one
@@ -19,18 +19,21 @@
 
 namespace {
 
-template <int KS, int NB, bool ONES>
+template <int KS, int NB, bool ONES, int KT>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
+  // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key
+  constexpr int NKB = KT / 32;               // 32-key blocks of S^T per tile
+  constexpr int VCH = KT / 8;                // 16-byte chunks per V^T row
   // ONES: D < 32*NB, so V^T row D is a spare MFMA row; it is filled with ones and the PV
   // MFMA then accumulates the softmax denominator there (no VALU row-sum in the loop).
   constexpr int KSLOTS = (2 * KS) | 1;       // 16-byte slots per K row (odd)
   constexpr int KCH = 2 * KS;                // chunks per K row that are written
   constexpr int DV = NB * 32;
-  constexpr int VROW = 136;                  // bytes
-  constexpr int K_BYTES = 64 * KSLOTS * 16;
+  constexpr int VROW = KT * 2 + 8;           // bytes; (VROW/8) odd -> conflict-free ds_read_b64
+  constexpr int K_BYTES = KT * KSLOTS * 16;
   constexpr int V_BYTES = DV * VROW;
-  constexpr int NCH_K = (64 * KCH + 255) / 256;
-  constexpr int NCH_V = (DV * 8 + 255) / 256;
+  constexpr int NCH_K = (KT * KCH + 255) / 256;
+  constexpr int NCH_V = (DV * VCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
   unsigned char* ksm = smem;
   unsigned char* vsm = smem + K_BYTES;
@@ -71,21 +74,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     const int q = tid + 256 * i;
     const int key = q / KCH, ch = q - key * KCH;
     k_key[i] = key;
-    k_lds[i] = (q < 64 * KCH) ? (key * KSLOTS + ch) * 16 : -1;
-    koff[i] = (q < 64 * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;   // pad chunks read as zeros
+    k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
+    koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;   // pad chunks read as zeros
   }
 #pragma unroll
   for (int i = 0; i < NCH_V; ++i) {
     const int q = tid + 256 * i;
-    const int d = q >> 3, kc = q & 7;
+    const int d = q / VCH, kc = q - d * VCH;
     v_d[i] = d;
     v_kc[i] = kc;
-    v_lds[i] = (q < DV * 8 && d < D) ? d * VROW + kc * 16 : -1;     // rows >= D are written once, below
-    voff[i] = (q < DV * 8 && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
+    v_lds[i] = (q < DV * VCH && d < D) ? d * VROW + kc * 16 : -1;     // rows >= D are written once, below
+    voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
   }
   // rows D .. DV-1 of the V^T tile never change: ones (denominator row, when ONES) / zeros
-  for (int q = tid; q < DV * 8; q += 256) {
-    const int d = q >> 3, kc = q & 7;
+  for (int q = tid; q < DV * VCH; q += 256) {
+    const int d = q / VCH, kc = q - d * VCH;
     if (d >= D) {
       const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
       u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   u32x4 kreg[NCH_K], vreg[NCH_V];
 
   auto load_tile = [&](int key0) __attribute__((always_inline)) {
-    const bool tail = key0 + 64 > p.nk;                  // wave-uniform
+    const bool tail = key0 + KT > p.nk;                  // wave-uniform
     const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
 #pragma unroll
     for (int i = 0; i < NCH_K; ++i) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     }
   };
   auto store_tile = [&](int key0) __attribute__((always_inline)) {
-    const bool tail = key0 + 64 > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
+    const bool tail = key0 + KT > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
 #pragma unroll
     for (int i = 0; i < NCH_K; ++i)
       if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
@@ -145,20 +148,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   float m_run = -1e30f;                             // running max, already multiplied by c
   float l_run = 0.f;                                // VALU row-sum (only when !ONES)
 
-  const int ntiles = (p.nk + 63) / 64;
+  const int ntiles = (p.nk + KT - 1) / KT;
   load_tile(0);
   for (int t = 0; t < ntiles; ++t) {
-    const int key0 = t * 64;
+    const int key0 = t * KT;
     __syncthreads();            // previous tile fully consumed
     store_tile(key0);
     __syncthreads();
-    if (t + 1 < ntiles) load_tile(key0 + 64);   // in flight during the MFMA / softmax block below
+    if (t + 1 < ntiles) load_tile(key0 + KT);   // in flight during the MFMA / softmax block below
 
     // ---- S^T = K Q^T for two 32-key blocks ----
-    f32x16 acc_s[2];
+    f32x16 acc_s[NKB];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const u32x4 kf = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
       }
     }
     // ---- masks only on the tiles that need them (wave-uniform) ----
-    if (key0 + 64 > p.nk || p.causal) {
+    if (key0 + KT > p.nk || p.causal) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -177,9 +180,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
         }
     }
     // ---- online softmax, query on the lane ----
-    float mx = fmaxf(acc_s[0][0], acc_s[1][0]);
+    float mx = acc_s[0][0];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(acc_s[0][i], acc_s[1][i]));
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * c);
     if (__any(m_new > m_run)) {   // some query's max moved: rescale everything at the old max once
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     }
     float psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][i], c, -m_run));
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 
     // ---- O^T += V^T P^T  (row D of V^T is ones when ONES: accumulates the denominator) ----
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 2 * NKB; ++ks) {
       const int kb = ks >> 1, half = ks & 1;
       u32x4 pf;
       pf.x = pack2(acc_s[kb][8 * half + 0], acc_s[kb][8 * half + 1]);
@@ -257,8 +262,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
-  if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false>), grid, dim3(256), 0, s, p);
+  // 128-key tiles for the long self-attention sequences at head dims <= 96 (register budget);
+  // 64-key tiles otherwise (cross-attention has 77 keys, d = 160 needs the registers for O^T)
+  constexpr bool BIG_OK = KS <= 6;
+  const bool big = BIG_OK && p.nk >= 512;
+  if (p.D < 32 * NB) {
+    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64>), grid, dim3(256), 0, s, p);
+  } else {
+    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, 64>), grid, dim3(256), 0, s, p);
+  }
   SASPA_CHECK_LAUNCH();
   return 0;
 }

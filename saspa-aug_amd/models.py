@@ -87,7 +87,8 @@ def project_vt(x, wv, nk):
     b, n, k = x.shape
     c = wv.shape[0]
     ld = ops.round8(nk)
-    vt = torch.zeros((b, c, ld), device=x.device, dtype=x.dtype)
+    # pad columns (keys >= nk) must be zero for the unfused PV GEMM; none exist when nk % 8 == 0
+    vt = (torch.zeros if ld != nk else torch.empty)((b, c, ld), device=x.device, dtype=x.dtype)
     ops.gemm_batched(wv, wv.stride(0), (0, 0), x, x.stride(1), (x.stride(0), 0), vt, ld, (c * ld, 0), c, nk, k, b, 1)
     return vt
 

@@ -122,4 +122,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Raw buffer loads: 32-bit per-lane byte offset + scalar byte offset against a 128-bit
+// descriptor; an offset >= num_records (2 GiB here) returns zeros -- that is how M / N / halo
+// padding is produced with no branch and no zero-fill (kInvalid below).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kInvalid = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+typedef __attribute__((address_space(3))) void lds_void_t;
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

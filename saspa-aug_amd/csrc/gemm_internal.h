@@ -1,0 +1,12 @@
+// Internal (not exported) entry points shared between the GEMM translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "saspa_hip.h"
+
+// 8-wave 256 x (64*fn) ping-pong kernel (saspa_gemm_pp.hip).  bf16, "fast" operand layout only
+// (see saspa_gemm.hip); fn in {4, 5}.  Returns SASPA_ERANGE if the problem is not eligible.
+__attribute__((visibility("hidden"))) int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn);
+__attribute__((visibility("hidden"))) bool saspa_gemm_pp_eligible(const SaspaGemmParams& p);
+// split-K reduce + epilogue launch shared by both variants (saspa_gemm.hip)
+__attribute__((visibility("hidden"))) int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit);

@@ -26,20 +26,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_internal.h"
 
 namespace {
-
-// Raw buffer loads: 32-bit per-lane byte offset + scalar byte offset against a 128-bit
-// descriptor; an offset >= num_records (2 GiB here) returns zeros -- that is how M / N / halo
-// padding is produced with no branch and no zero-fill (kInvalid below).
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr unsigned kInvalid = 0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ u32x4 buf_load(rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -102,29 +91,44 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
     } else if (staged) {
     constexpr int CP = BN + 8;                       // LDS row pitch in elements (16-byte pad)
     T* ct = reinterpret_cast<T*>(lds);
+    // bias + time-embedding row of the wave's FIRST image, loaded once per column fragment (WN loads in
+    // flight together instead of one dependent L2 round trip per accumulator fragment); rows of a later
+    // image (tiles that straddle images) take the reload path
+    const int m0 = cbm * BM + wm * (16 * WM);
+    const int img0 = min(m0, p.M - 1) / hw;
+    const int mnext = (img0 + 1) * hw;
+    float4 add[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = cbn * BN + wn * (16 * WN) + j * 16 + fg * 4;
+      add[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.N) {   // N % 8 == 0: a 4-vector never straddles N
+        if (p.bias) add[j] = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.rowvec) {
+          const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)img0 * p.ldrv + n);
+          add[j].x += r4.x; add[j].y += r4.y; add[j].z += r4.z; add[j].w += r4.w;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int mrow = wm * (16 * WM) + i * 16 + frow;
       const int m = cbm * BM + mrow;
-      const float* rv = nullptr;
-      if (p.rowvec && m < p.M) rv = p.rowvec + (long long)(m / hw) * p.ldrv;
+      const bool other = p.rowvec && m >= mnext && m < p.M;
+      const float* rvd = other ? p.rowvec + (long long)(m / hw) * p.ldrv : nullptr;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int ncol = wn * (16 * WN) + j * 16 + fg * 4;
         const int n = cbn * BN + ncol;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (n < p.N) {   // N % 8 == 0: a 4-vector never straddles N
-          if (p.bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-          }
-          if (rv) {
-            const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= p.alpha;   // SiLU (if any) is applied in the read phase
+        float v[4] = {acc[i][j][0] + add[j].x, acc[i][j][1] + add[j].y, acc[i][j][2] + add[j].z, acc[i][j][3] + add[j].w};
+        if (other && n < p.N) {
+          const float4 a4 = *reinterpret_cast<const float4*>(rvd + n);
+          const float4 c4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[0] = acc[i][j][0] + (c4.x + a4.x); v[1] = acc[i][j][1] + (c4.y + a4.y);
+          v[2] = acc[i][j][2] + (c4.z + a4.z); v[3] = acc[i][j][3] + (c4.w + a4.w);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;   // SiLU (if any) is applied in the read phase
         Elem<T>::store4(ct + mrow * CP + ncol, v);
       }
     }
@@ -497,7 +501,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
 // the fragment reads apply the same XOR.  Out-of-range lanes (M / N edge, halo) use an offset
 // beyond num_records and land as zeros.  Two LDS stages: the DMA of tile t+1 is in flight
 // during the MFMAs of tile t; one barrier per K-tile.
-typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE>
 __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 : 2) void gemm_dma_kernel(const SaspaGemmParams p,
@@ -817,12 +820,7 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
     else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
   }
   SASPA_CHECK_LAUNCH();
-  if (ksplit > 1) {
-    long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
-    SASPA_CHECK_LAUNCH();
-  }
+  if (ksplit > 1) return saspa_gemm_splitk_reduce(p, s, ksplit);
   return 0;
 }
 
@@ -841,6 +839,13 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   if (force_tile == 22) return launch<T, 2, 2>(p, s, ksplit);
   if (force_tile == 41) return launch<T, 4, 1>(p, s, ksplit);
   if (p.N <= 32) return launch<T, 4, 1>(p, s, 1);
+  if constexpr (sizeof(T) == 2) {
+    // long-K layers: 8-wave 256 x 256/320 ping-pong kernel (saspa_gemm_pp.hip)
+    static const int pp_mode = getenv("SASPA_GEMM_PP") ? atoi(getenv("SASPA_GEMM_PP")) : 0;   // 0 off, 1 auto, 4/5 force FN
+    if (pp_mode && saspa_gemm_pp_eligible(p) && nb == 1) {
+      if (pp_mode >= 4) return saspa_gemm_pp_launch(p, s, ksplit, pp_mode);
+    }
+  }
   const int bn = n160 ? 160 : 128;
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
   if (tiles >= 160 && p.N > 64) return n160 ? launch<T, 4, 5>(p, s, ksplit) : launch<T, 4, 4>(p, s, ksplit);
@@ -848,6 +853,15 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
+  long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
+  else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (!pp) return SASPA_EINVAL;

@@ -1,0 +1,540 @@
+// Ping-pong implicit-GEMM for the long-K bf16 layers (3x3 convs of UNet / ControlNet / VAE, the
+// wide projections): one workgroup of 8 waves per CU owns a 256 x (64*FN) output tile.
+//
+// Why a second kernel: the 4-wave 128x160 kernel of saspa_gemm.hip fetches 1 byte of operand per
+// ~71 MFMA flops; at the ~90 GB/s a CU sustains through the LDS-DMA path that caps it near
+// 0.9 PFLOP/s whatever the schedule (profiles/r1_*: DMA time and MFMA time add).  A 256x256
+// (256x320) tile needs 128 (142) flops per fetched byte, and the two wave groups below keep the
+// MFMA pipe busy while the other group issues its LDS reads and DMA.
+//
+// Structure (cdna_hip_programming.md, "256^2 8-phase template", re-derived for an M-sliced phase
+// split and the im2col A operand):
+//   * waves 2 (M) x 4 (N); a wave owns 128 x (16*FN) outputs = 8 x FN accumulator fragments
+//     (D^T form: weights are the MFMA A operand, so a lane holds 4 consecutive channels).
+//   * K-tile = 64 bf16 (128-byte LDS rows, chunk ^= row & 7 swizzle applied on the DMA source
+//     side and on the fragment reads); 2 LDS buffers of (256 + BN) rows.
+//   * a K-tile is 4 phases; phase P multiplies rows [32P, 32P+32) of each wave's 128 rows against
+//     the wave's whole B slice (B fragments are read once per K-tile, in phase 0):
+//         ds_read fragments | issue LDS-DMA pieces | counted vmcnt | s_barrier | MFMAs | s_barrier
+//   * the wm = 1 group runs one barrier behind the wm = 0 group: while one group is in its MFMA
+//     block the other does its reads / DMA issue on the same SIMDs (one wave of each per SIMD).
+//   * slots are restaged as soon as they are free: A slice P of tile t is overwritten with slice P
+//     of tile t+2 one phase after its last read (each group stages only its own A rows, so its
+//     own barrier orders read -> overwrite); the B fragment reads of phase 0 are retired by a
+//     counted lgkmcnt BEFORE that phase's first barrier, so B pieces follow from phase 1 on.
+//     Two pieces per wave per phase (one A, one B; the 5th B piece of BN = 320 rides with slice 3).
+//   * RAW: one counted vmcnt per K-tile (phase 3, ahead of its first barrier, leaving the six
+//     pieces of phases 1-3 in flight): everything older -- the whole next tile -- has landed
+//     before the phase that first reads it.  Nothing is drained to vmcnt(0) inside the loop.
+//   * tail: tiles beyond the K range are "staged" with out-of-range offsets (the DMA writes zeros
+//     into slots nobody reads again), which keeps the per-wave vmcnt arithmetic uniform.
+//   * epilogue: two 128-row halves through LDS (bias / time-embedding row / alpha, then
+//     SiLU / residual on the coalesced 16-byte store pass); split-K writes fp32 slabs.
+#include <cstdlib>
+
+#include "common.h"
+#include "gemm_internal.h"
+
+namespace {
+
+typedef bf16_t T;
+
+__device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int FN, bool PW, bool UP, bool ONEBAR>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, const int ntiles_abl) {
+  // diagnostic ablation (tools/gemm_ablate.py, `make ABLATION=1` only): bits 28..31 of the tile count
+  //   1: no MFMA   2: no fragment reads   4: no DMA issue   8: no barriers
+  const int ntiles = ntiles_abl & 0x07ffffff;
+#ifdef SASPA_GEMM_ABLATION
+  const int abl = (ntiles_abl >> 28) & 15;
+  const bool stamp = (ntiles_abl >> 27) & 1;           // block 0 leaves (shader clocks, 100 MHz ticks) of its K loop in out[0..15]
+  unsigned long long st0 = 0, sr0 = 0, st1 = 0, sr1 = 0;
+#else
+  constexpr int abl = 0;
+#endif
+  constexpr int BM = 256, BN = 64 * FN, BK = 64, SZ = 2;
+  constexpr int STAGE = (BM + BN) * 8;                 // u32x4 per LDS buffer
+  constexpr int CP = BN + 8;                           // epilogue row pitch (elements)
+  constexpr int EPI = 128 * CP * SZ / 16;              // u32x4 for one 128-row half of the output tile
+  constexpr int NLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+  __shared__ u32x4 lds[NLDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int lr = lane >> 3;                            // row inside an 8-row DMA piece
+  const int kcs = (lane & 7) ^ lr;                     // logical 16-byte chunk this lane fetches (source-side swizzle)
+
+  const int nbn = (p.N + BN - 1) / BN;
+  const int G = gridDim.x;
+  int tile;
+  {
+    const int L = blockIdx.x;
+    const int qd = G >> 3, rr = G & 7, xcd = L & 7, idx = L >> 3;
+    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
+  }
+  const int z = blockIdx.z;
+  const int i1 = z / p.nb2, i2 = z - i1 * p.nb2;
+  const T* a0 = reinterpret_cast<const T*>(p.a0) + (i1 * p.sa1 + i2 * p.sa2);
+  const T* a1 = reinterpret_cast<const T*>(p.a1);
+  const T* w = reinterpret_cast<const T*>(p.w) + (i1 * p.sw1 + i2 * p.sw2);
+  const long long ooff = i1 * p.so1 + i2 * p.so2;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * kt_per;
+  const int nk = max(0, min(nk_all, kt0 + kt_per) - kt0);
+
+  const int hw = p.hout * p.wout;
+  const int ctot = p.c0 + p.c1;
+  const int hv = UP ? 2 * p.hin : p.hin, wv = UP ? 2 * p.win : p.win;
+  // A descriptors: for the 3x3 / pad 1 window the base is moved back by one row + one pixel so that the
+  // tap offset (dy*win + dx) * pitch is a non-negative SCALAR offset (no per-lane arithmetic per tap)
+  const int back = (PW || UP) ? 0 : p.win + 1;
+  const T* a0s = a0 - (long long)back * p.lda0;
+  const T* a1s = p.c1 > 0 ? a1 - (long long)back * p.lda1 : a0s;
+  // descriptors are rebuilt from (pointer, record count) scalars whenever the staged tile changes source:
+  // zero records = every access out of range -> the DMA writes zeros and touches no memory
+  auto make_desc = [](const T* base, bool live) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, live ? 0x7fffffff : 0, 0x00020000);
+  };
+  const rsrc_t rsn = make_desc(w, false);
+
+  // ---- per-lane loader state: one A row per phase slice (4 slices), one weight row ----
+  //   PW        va = byte offset of (row m, chunk kcs) in the current source
+  //   3x3       va = same for the window's centre pixel; vb = pixel index | (8 halo-tap "outside" bits << 24)
+  //   upsample  va = first pixel of the image, vb = 9-bit tap validity, vc = packed top-left corner (generic path)
+  // Rows beyond M are aliased to row 0: they are computed and never stored.
+  int bm = 0, bn = 0;
+  int va[4], vb[PW ? 1 : 4], vc[UP ? 4 : 1];
+  unsigned offb0 = 0;                                  // weight row (8*wave + lr) of the tile, chunk kcs; piece i adds 64 rows (scalar)
+  int nrows = 0;                                       // valid weight rows of the tile (wave-uniform)
+  int ku = 0, cu = 0, dyu = 0, dxu = 0, staged = 0;    // K state of the NEXT tile to stage (wave-uniform)
+  int src = -1;                                        // source tensor va[] is currently scaled for
+  const int arow0 = wm * 128 + (wave & 3) * 8 + lr;    // A row of slice 0 handled by this lane; + 32 per slice
+
+  auto setup_tile = [&](int t) __attribute__((always_inline)) {
+    bm = t / nbn;
+    bn = t - bm * nbn;
+    if (!PW) {
+      int m = bm * BM + arow0;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / p.wout;
+      int ox = rem - oy * p.wout;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool live = m < p.M;
+        const int eb = live ? b : 0, ey = live ? oy : 0, ex = live ? ox : 0;
+        const int iy0 = ey * p.stride - p.pad, ix0 = ex * p.stride - p.pad;
+        if (UP) {
+          va[s] = eb * p.hin * p.win;
+          vc[UP ? s : 0] = ((iy0 + 1) << 16) | (ix0 + 1);
+          int mask = 0;
+          for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx)
+              if ((unsigned)(iy0 + ty) < (unsigned)hv && (unsigned)(ix0 + tx) < (unsigned)wv) mask |= 1 << (ty * 3 + tx);
+          vb[PW ? 0 : s] = mask;
+        } else {
+          // "outside" bit of the 8 non-centre taps (the centre tap of a live row is always inside)
+          int outside = 0;
+#pragma unroll
+          for (int tb = 0; tb < 9; ++tb) {
+            if (tb == 4) continue;
+            const int ty = tb / 3, tx = tb - ty * 3;
+            if (!((unsigned)(iy0 + ty) < (unsigned)hv && (unsigned)(ix0 + tx) < (unsigned)wv)) outside |= 1 << (tb < 4 ? tb : tb - 1);
+          }
+          vb[PW ? 0 : s] = (eb * p.hin * p.win + (ey * p.stride) * p.win + ex * p.stride) | (outside << 24);
+        }
+        m += 32;
+        ox += 32;
+        while (ox >= p.wout) { ox -= p.wout; ++oy; }
+        while (oy >= p.hout) { oy -= p.hout; ++b; }
+      }
+    }
+    offb0 = (unsigned)((bn * BN + wave * 8 + lr) * p.ldw * SZ + kcs * 16);
+    nrows = p.N - bn * BN;                             // N % 8 == 0: validity is uniform over an 8-row piece
+    ku = kt0 * BK;
+    const int tapu = ku / ctot;
+    cu = ku - tapu * ctot;
+    dyu = tapu / p.kw;
+    dxu = tapu - dyu * p.kw;
+    staged = 0;
+    src = -1;
+  };
+
+  // wave-uniform description of the tile being staged
+  bool sv = false;
+  rsrc_t rs = rsn, rswv = rsn;
+  int ldsz = 0, soff = 0, soffw = 0, sdy = 0, sdx = 0, bsh = 0, tapbit = 0;
+  unsigned amask = 0;
+  auto begin_stage = [&]() __attribute__((always_inline)) {
+    sv = staged < nk;
+    const bool s0 = cu < p.c0;
+    ldsz = (s0 ? p.lda0 : p.lda1) * SZ;
+    rs = make_desc(s0 ? a0s : a1s, sv);
+    rswv = make_desc(w, sv);
+    soff = (s0 ? cu : cu - p.c0) * SZ;
+    soffw = ku * SZ;
+    if (!UP) {
+      if (src != (s0 ? 0 : 1)) {
+        // (re)scale the per-lane offsets for this source's row pitch: once per tap and source, not per tile
+        src = s0 ? 0 : 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          int px;
+          if (PW) {
+            const int m = bm * BM + arow0 + 32 * s;
+            px = m < p.M ? m : 0;
+          } else {
+            px = vb[PW ? 0 : s] & 0xffffff;
+          }
+          va[s] = (int)(__umul24((unsigned)px, (unsigned)ldsz) + (unsigned)(kcs * 16));
+        }
+      }
+      if (!PW) {
+        const int tb = dyu * 3 + dxu;
+        soff += (dyu * p.win + dxu) * ldsz;
+        bsh = 7 - (tb < 4 ? tb : tb - 1);
+        amask = tb == 4 ? 0u : 0x80000000u;
+      }
+    } else {
+      tapbit = dyu * 3 + dxu;
+      sdy = dyu;
+      sdx = dxu;
+    }
+    // advance to the following tile
+    ++staged;
+    ku += BK;
+    cu += BK;
+    if (cu >= ctot) {
+      cu -= ctot;
+      if (++dxu == p.kw) { dxu = 0; ++dyu; }
+    }
+  };
+  // LDS element (u32x4) index of the READ buffer (cur) and of the other one; swapped every K-tile
+  int cur = 0, oth = STAGE;
+  // fragment read offsets of this lane inside a buffer (kk = 0 / 1: swizzled chunk differs in bit 2)
+  const int swz0 = fg ^ (frow & 7);
+  int ra0 = (wm * 128 + frow) * 8 + swz0, ra1 = ra0 ^ 4;
+  int rb0 = (BM + wn * (16 * FN) + frow) * 8 + swz0, rb1 = rb0 ^ 4;
+  const int dma_a = (wm * 128 + (wave & 3) * 8) * 8;   // + 32 rows per slice
+  const int dma_b = (BM + wave * 8) * 8;               // + 64 rows per piece
+
+  auto stage_a = [&](const int s, const int buf) __attribute__((always_inline)) {
+    unsigned off;
+    if (UP) {
+      const int iy = ((vc[UP ? s : 0] >> 16) - 1 + sdy) >> 1, ix = ((vc[UP ? s : 0] & 0xffff) - 1 + sdx) >> 1;
+      const int px = va[s] + iy * p.win + ix;
+      const bool ok = ((vb[PW ? 0 : s] >> tapbit) & 1) != 0;
+      off = ok ? __umul24((unsigned)px, (unsigned)ldsz) + (unsigned)(kcs * 16) : kInvalid;
+    } else if (PW) {
+      off = (unsigned)va[s];
+    } else {
+      // bit 31 set (out of range -> zeros) iff this tap falls outside the image for this row
+      off = (((unsigned)vb[PW ? 0 : s] << bsh) & amask) | (unsigned)va[s];
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + buf + dma_a + s * 32 * 8), 16, (int)off, soff, 0, 0);
+  };
+  auto stage_b = [&](const int i, const int buf) __attribute__((always_inline)) {
+    // rows beyond N (wave-uniform per 8-row piece): a scalar offset beyond num_records -> zeros
+    const bool ok = (wave + 8 * i) * 8 < nrows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rswv, (lds_void_t*)(lds + buf + dma_b + i * 64 * 8), 16, (int)(ok ? offb0 : kInvalid),
+                                             soffw + i * 64 * p.ldw * SZ, 0, 0);
+  };
+  // B pieces that travel with A slice s: piece s for s < 3, pieces 3 .. FN-1 with slice 3
+  auto stage_slice = [&](const int s, const int buf) __attribute__((always_inline)) {
+    stage_a(s, buf);
+    if (s < 3) {
+      stage_b(s, buf);
+    } else {
+#pragma unroll
+      for (int i = 3; i < FN; ++i) stage_b(i, buf);
+    }
+  };
+
+  f32x4 acc[8][FN];
+  u32x4 wb[FN][2], xa[2][2];
+#ifdef SASPA_GEMM_ABLATION
+#pragma unroll
+  for (int j = 0; j < FN; ++j) wb[j][0] = wb[j][1] = u32x4{(unsigned)j, 0u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xa[i][0] = xa[i][1] = u32x4{(unsigned)i, 1u, 0x3f803f80u, 0x3f803f80u};
+#endif
+
+  // one phase of the tile in `cur`: fragment reads of slice P (+ all B fragments in phase 0), DMA issue of
+  // slice SS into buffer sbuf, then barrier | MFMAs | barrier
+  auto phase = [&](const int P, const int SS, const int sbuf, const bool sync) __attribute__((always_inline)) {
+    if (!(abl & 2)) {
+      if (P == 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          wb[j][0] = lds[rb0 + j * 16 * 8];
+          wb[j][1] = lds[rb1 + j * 16 * 8];
+        }
+        __builtin_amdgcn_sched_barrier(0);             // B reads are issued (and counted) before the A reads
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        xa[i][0] = lds[ra0 + (P * 32 + i * 16) * 8];
+        xa[i][1] = lds[ra1 + (P * 32 + i * 16) * 8];
+      }
+    }
+    if (!(abl & 4)) stage_slice(SS, sbuf);
+    // phase 3: everything but this K-tile's slices 0..2 (six pieces) has landed, i.e. the whole next tile
+    if (sync && P == 3) wait_vm<6>();
+    // phase 0: the B fragment reads (issued first) are complete before this wave passes the barrier, so the
+    // other group may restage the B slot in ITS next phase
+    if (sync && P == 0) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    if (sync && !(abl & 8)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    if (abl & 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { asm volatile("" ::"v"(xa[i][0])); asm volatile("" ::"v"(xa[i][1])); }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(wb[j][0])); asm volatile("" ::"v"(wb[j][1])); }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) mma(wb[j][kk], xa[i][kk], acc[P * 2 + i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (sync && !(abl & 8)) __builtin_amdgcn_s_barrier();
+  };
+
+  setup_tile(tile);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+      if (ONEBAR) {
+        // ---- one barrier per K-tile, waves otherwise free-running: the two waves of a SIMD interleave
+        //      their MFMA blocks with each other's reads / DMA issue on their own ----
+        begin_stage();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) stage_slice(s, cur);
+#ifdef SASPA_GEMM_ABLATION
+        if (stamp) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        for (int t = 0; t < nk; ++t) {
+          wait_vm<0>();                                // this wave's share of tile t has landed
+          if (!(abl & 8)) __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading tile t-1 (-> oth is free)
+          begin_stage();                               // tile t+1 -> oth, issued slice by slice between the MFMA blocks
+          phase(0, 0, oth, false);
+          phase(1, 1, oth, false);
+          phase(2, 2, oth, false);
+          phase(3, 3, oth, false);
+          const int d = oth - cur;
+          ra0 += d; ra1 += d; rb0 += d; rb1 += d;
+          cur += d;
+          oth -= d;
+        }
+#ifdef SASPA_GEMM_ABLATION
+        if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+      } else {
+      // ---- prologue: tile 0 complete, slices 0..2 of tile 1 in flight ----
+      begin_stage();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) stage_slice(s, cur);
+      begin_stage();
+#pragma unroll
+      for (int s = 0; s < 3; ++s) stage_slice(s, oth);
+      wait_vm<6>();
+      __builtin_amdgcn_s_barrier();
+      if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm = 1 group runs one barrier behind
+#ifdef SASPA_GEMM_ABLATION
+      if (stamp) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+      for (int t = 0; t < nk; ++t) {
+        // tile t is multiplied out of `cur`.  Phase 0 completes tile t+1 (slice 3 -> oth); phases 1..3 put
+        // slices 0..2 of tile t+2 into the slots of `cur` that phases 0..2 have just released.
+        phase(0, 3, oth, true);
+        begin_stage();
+        phase(1, 0, cur, true);
+        phase(2, 1, cur, true);
+        phase(3, 2, cur, true);
+        const int d = oth - cur;
+        ra0 += d; ra1 += d; rb0 += d; rb1 += d;
+        cur += d;
+        oth -= d;
+      }
+#ifdef SASPA_GEMM_ABLATION
+      if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+      if (wm == 0) __builtin_amdgcn_s_barrier();       // barrier counts of the two groups match again
+      }
+      wait_vm<0>();                                    // tail DMAs (zeros) must not land in the epilogue's LDS
+      if (cur != 0) {                                  // next output tile starts from buffer 0 again
+        ra0 -= STAGE; ra1 -= STAGE; rb0 -= STAGE; rb1 -= STAGE;
+        cur = 0;
+        oth = STAGE;
+      }
+    }
+    __syncthreads();
+
+    const int cbm = bm, cbn = bn;
+    const int next = tile + G;
+    const bool has_next = next < ntiles;
+
+    // ---- epilogue ----
+    T* out = reinterpret_cast<T*>(p.out) + ooff;
+    const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + ooff : nullptr;
+    if (gridDim.y > 1) {
+      float* ws = p.workspace + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = cbm * BM + wm * 128 + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = cbn * BN + wn * (16 * FN) + j * 16 + fg * 4;
+          if (n >= p.N) continue;
+          *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+    } else {
+      T* ct = reinterpret_cast<T*>(lds);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+          // bias + time-embedding row of the half-tile's FIRST image, loaded once per column fragment (5 loads
+          // in flight together instead of one dependent L2 round trip per accumulator fragment); rows that
+          // belong to a later image (only when H*W < 128) take the reload path
+          const int m0 = cbm * BM + h * 128;
+          const int img0 = min(m0, p.M - 1) / hw;
+          const int mnext = (img0 + 1) * hw;             // first row of the next image
+          float4 add[FN];
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int n = cbn * BN + wn * (16 * FN) + j * 16 + fg * 4;
+            add[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.N) {
+              if (p.bias) add[j] = *reinterpret_cast<const float4*>(p.bias + n);
+              if (p.rowvec) {
+                const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)img0 * p.ldrv + n);
+                add[j].x += r4.x; add[j].y += r4.y; add[j].z += r4.z; add[j].w += r4.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int mrow = i * 16 + frow;
+            const int m = m0 + mrow;
+            const bool other = p.rowvec && m >= mnext && m < p.M;
+            const float* rvd = other ? p.rowvec + (long long)(m / hw) * p.ldrv : nullptr;   // rare: row of a later image
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const int ncol = wn * (16 * FN) + j * 16 + fg * 4;
+              const int n = cbn * BN + ncol;
+              float v[4] = {acc[i][j][0] + add[j].x, acc[i][j][1] + add[j].y, acc[i][j][2] + add[j].z, acc[i][j][3] + add[j].w};
+              if (other && n < p.N) {
+                const float4 a4 = *reinterpret_cast<const float4*>(rvd + n);
+                const float4 c4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                // same association as the common path: acc + (bias + rowvec)
+                v[0] = acc[i][j][0] + (c4.x + a4.x); v[1] = acc[i][j][1] + (c4.y + a4.y);
+                v[2] = acc[i][j][2] + (c4.z + a4.z); v[3] = acc[i][j][3] + (c4.w + a4.w);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+              Elem<T>::store4(ct + mrow * CP + ncol, v);
+            }
+          }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        for (int q = tid; q < 128 * CPR; q += 512) {
+          const int row = q / CPR, ch = q - row * CPR;
+          const int m = cbm * BM + h * 128 + row, n = cbn * BN + ch * 8;
+          if (m >= p.M || n >= p.N) continue;
+          u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
+          if (res || p.act == SASPA_ACT_SILU) {
+            float a[8];
+            unpack8(__builtin_bit_cast(uint4, c4), a);
+            if (p.act == SASPA_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
+            }
+            if (res) {
+              float b[8];
+              Elem<bf16_t>::load_chunk(res + (long long)m * p.ldr + n, b);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] += b[e];
+            }
+            c4 = __builtin_bit_cast(u32x4, pack8(a));
+          }
+          *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
+        }
+        __syncthreads();
+      }
+    }
+#ifdef SASPA_GEMM_ABLATION
+    if (stamp && tid == 0) {
+      // diagnostics: the caller's `out` allocation extends 4 x 8 bytes per workgroup beyond M rows
+      __threadfence();
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<T*>(p.out) + (long long)p.M * p.ldo) + 4 * blockIdx.x;
+      o[0] = sr0;
+      o[1] = sr1;
+      o[2] = st1 - st0;
+      o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (!has_next) break;
+    tile = next;
+    setup_tile(tile);
+  }
+}
+
+template <int FN, bool ONEBAR>
+int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
+  constexpr int BM = 256, BN = 64 * FN;
+  const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  const int zy = ksplit * p.nb1 * p.nb2;
+  int gx = tiles;
+  if ((long long)tiles * zy > 256) gx = max(1, min(tiles, 256 / zy));
+  dim3 grid(gx, ksplit, p.nb1 * p.nb2);
+  const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
+  static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;   // diagnostics only
+  static const int stamp = getenv("SASPA_GEMM_STAMP") ? (atoi(getenv("SASPA_GEMM_STAMP")) & 1) : 0;
+  const int ta = tiles | (abl << 28) | (stamp << 27);
+  if (pw) hipLaunchKernelGGL((gemm_pp_kernel<FN, true, false, ONEBAR>), grid, dim3(512), 0, s, p, ta);
+  else if (p.upsample) hipLaunchKernelGGL((gemm_pp_kernel<FN, false, true, ONEBAR>), grid, dim3(512), 0, s, p, ta);
+  else hipLaunchKernelGGL((gemm_pp_kernel<FN, false, false, ONEBAR>), grid, dim3(512), 0, s, p, ta);
+  SASPA_CHECK_LAUNCH();
+  if (ksplit > 1) return saspa_gemm_splitk_reduce(p, s, ksplit);
+  return 0;
+}
+
+}  // namespace
+
+bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
+  const int ctot = p.c0 + p.c1;
+  if (p.dtype != SASPA_BF16 || p.act == SASPA_ACT_GEGLU) return false;
+  if ((ctot % 64) != 0 || (p.c1 > 0 && (p.c0 % 64) != 0)) return false;        // a K-tile lies in one tap of one source
+  if (p.upsample && !(p.pad <= 1 && p.hin < 16000 && p.win < 16000)) return false;
+  if ((p.N % 8) != 0 || (p.ldo % 8) != 0 || (p.residual && (p.ldr % 8) != 0)) return false;
+  return true;
+}
+
+int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn) {
+  if (!saspa_gemm_pp_eligible(p)) return SASPA_ERANGE;
+  if (fn == 5) return launch_pp<5, false>(p, s, ksplit);
+  if (fn == 4) return launch_pp<4, false>(p, s, ksplit);
+  if (fn == 15) return launch_pp<5, true>(p, s, ksplit);
+  if (fn == 14) return launch_pp<4, true>(p, s, ksplit);
+  return SASPA_ERANGE;
+}

@@ -1,0 +1,29 @@
+"""Per-workgroup K-loop timeline and in-kernel clock of the ping-pong GEMM (diagnostic; needs `make ABLATION=1`)."""
+import os, sys, time
+os.environ.setdefault("SASPA_GEMM_PP", "5"); os.environ["SASPA_GEMM_STAMP"] = "1"
+import torch
+sys.path.insert(0, '.')
+import saspa_aug_amd  # noqa: F401
+from saspa_aug_amd import ops
+dev = torch.device('cuda:0')
+x = torch.randn(16, 64, 64, 640, device=dev).bfloat16()
+w = (torch.randn(320, 5760, device=dev) / 70).bfloat16()
+big = torch.zeros(17, 64, 64, 320, device=dev, dtype=torch.bfloat16)
+out = big[:16]
+t0 = time.time()
+while time.time() - t0 < 2.5:
+    for _ in range(200): ops.conv(x, w, kh=3, kw=3, pad=1, out=out)
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ops.conv(x, w, kh=3, kw=3, pad=1, out=out); e1.record(); torch.cuda.synchronize()
+st = big[16].reshape(-1).view(torch.int64)[:4 * 256].reshape(256, 4).cpu()
+s0, s1, clk, end = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+base = s0.min()
+f = lambda t: f"min {float(t.min()) / 100:7.1f} med {float(t.median()) / 100:7.1f} max {float(t.max()) / 100:7.1f}"
+print(f"ablate={os.environ.get('SASPA_GEMM_ABLATE', '0')} event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+print("loop start (us after first) :", f(s0 - base))
+print("loop end                    :", f(s1 - base))
+print("kernel end                  :", f(end - base))
+print("loop duration               :", f(s1 - s0))
+print("epilogue duration           :", f(end - s1))
+print(f"in-loop clock GHz: med {float((clk.float() / (s1 - s0).float()).median()) * 0.1:.3f}")

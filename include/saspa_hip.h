@@ -45,6 +45,10 @@ extern "C" {
  * tile t holds features [t*BN/2, (t+1)*BN/2) -- their value rows first, then their gate rows. */
 #define SASPA_ACT_GEGLU 3
 
+#define SASPA_GEMM_AUTO 0
+#define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
+#define SASPA_GEMM_WIDE 2  /* 8-wave 256x320 / 256x256 tile, one workgroup per CU */
+
 /* ---- implicit-GEMM convolution / linear ----------------------------------
  * out[m][n] = act( alpha * (sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n]) ) + residual[m][n]
  * where m = (b, oy, ox) and A is the im2col view of up to two channel-concatenated
@@ -88,6 +92,11 @@ typedef struct SaspaGemmParams {
    * epilogue launch).  Ignored when workspace is NULL, for batched problems or N % 4 != 0. */
   int ksplit;
   float* workspace;
+  /* kernel variant: SASPA_GEMM_AUTO lets the library choose per shape; the other values pin one
+   * (tests, tuning).  SASPA_GEMM_WIDE = one 8-wave workgroup per CU on a 256 x 256/320 tile
+   * (long-K bf16 layers); it returns SASPA_ERANGE for a problem it cannot run (fp32, fused
+   * GEGLU, channel counts that are not multiples of 64, windows other than 1x1 or 3x3/pad 1). */
+  int variant;
 } SaspaGemmParams;
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 

@@ -840,11 +840,24 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   if (force_tile == 41) return launch<T, 4, 1>(p, s, ksplit);
   if (p.N <= 32) return launch<T, 4, 1>(p, s, 1);
   if constexpr (sizeof(T) == 2) {
-    // long-K layers: 8-wave 256 x 256/320 ping-pong kernel (saspa_gemm_pp.hip)
-    static const int pp_mode = getenv("SASPA_GEMM_PP") ? atoi(getenv("SASPA_GEMM_PP")) : 0;   // 0 off, 1 auto, 4/5 force FN
-    if (pp_mode && saspa_gemm_pp_eligible(p) && nb == 1) {
-      if (pp_mode >= 4) return saspa_gemm_pp_launch(p, s, ksplit, pp_mode);
+    // long-K layers with enough 256-row tiles to fill the chip: 8-wave 256 x 320/256 kernel (saspa_gemm_pp.hip).
+    // SASPA_GEMM_PP: 0 = never (A/B knob), 4 / 5 / 14 / 15 = force a tile / loop flavour (tools/pp_check.py)
+    static const int pp_mode = getenv("SASPA_GEMM_PP") ? atoi(getenv("SASPA_GEMM_PP")) : 1;
+    const bool can = nb == 1 && saspa_gemm_pp_eligible(p);
+    if (p.variant == SASPA_GEMM_WIDE) {
+      if (!can) return SASPA_ERANGE;
+      return saspa_gemm_pp_launch(p, s, ksplit, (p.N % 320 == 0 || p.N % 256 != 0) ? 5 : 4);
     }
+    if (can && pp_mode >= 4) return saspa_gemm_pp_launch(p, s, ksplit, pp_mode);
+    if (can && pp_mode == 1 && p.variant == SASPA_GEMM_AUTO && p.K >= 960) {
+      const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
+      if (fn) {
+        const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
+        if (t >= 192) return saspa_gemm_pp_launch(p, s, 1, fn);   // one wave of tiles or more: no split-K
+      }
+    }
+  } else {
+    if (p.variant == SASPA_GEMM_WIDE) return SASPA_ERANGE;
   }
   const int bn = n160 ? 160 : 128;
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
@@ -902,6 +915,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     if (p.kh * p.kw > 31) return SASPA_ERANGE;
   }
   if (p.ksplit < 0 || p.ksplit > 64) return SASPA_ERANGE;
+  if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_WIDE) return SASPA_EINVAL;
   if (p.act == SASPA_ACT_GEGLU) {
     // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)
     const int bn = (p.N % 160) == 0 ? 160 : 128;

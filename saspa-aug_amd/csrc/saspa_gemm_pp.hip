@@ -525,8 +525,18 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
   const int ctot = p.c0 + p.c1;
   if (p.dtype != SASPA_BF16 || p.act == SASPA_ACT_GEGLU) return false;
   if ((ctot % 64) != 0 || (p.c1 > 0 && (p.c0 % 64) != 0)) return false;        // a K-tile lies in one tap of one source
-  if (p.upsample && !(p.pad <= 1 && p.hin < 16000 && p.win < 16000)) return false;
   if ((p.N % 8) != 0 || (p.ldo % 8) != 0 || (p.residual && (p.ldr % 8) != 0)) return false;
+  const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
+  if (!pw) {
+    // 3x3 / pad 1 window (any stride, optional nearest x2): 8 halo taps + an always-inside centre tap
+    if (p.kh != 3 || p.kw != 3 || p.pad != 1) return false;
+    const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
+    if ((p.hout - 1) * p.stride > hv - 1 || (p.wout - 1) * p.stride > wv - 1) return false;
+    if (p.upsample && (p.hin >= 16000 || p.win >= 16000)) return false;
+  }
+  // per-lane offsets are 24-bit pixel index x 24-bit pitch products
+  if ((long long)p.batch * p.hin * p.win >= (1ll << 24) || p.M >= (1 << 24)) return false;
+  if ((long long)p.lda0 * 2 >= (1ll << 24) || (long long)p.lda1 * 2 >= (1ll << 24)) return false;
   return true;
 }
 

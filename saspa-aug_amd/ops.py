@@ -14,6 +14,7 @@ from . import _lib
 ACT_NONE, ACT_SILU = 0, 1
 ACT_QUICK_GELU = 2  # saspa_activation only
 ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
+GEMM_AUTO, GEMM_TILED, GEMM_WIDE = 0, 1, 2   # SaspaGemmParams.variant
 
 
 # Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)
@@ -97,7 +98,7 @@ def _set_splitk(p, m, n, k, t):
 
 
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
-         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None):
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
     (pad channels zero)."""
@@ -130,13 +131,14 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.alpha, p.act = float(alpha), int(act)
     p.out, p.ldo = _ptr(out), _pitch4(out)
     p.nb1 = p.nb2 = 1
+    p.variant = int(variant)
     _ws = _set_splitk(p, p.M, p.N, p.K, x)  # noqa: F841
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
             (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None):
+def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0):
     """x: [..., K] (last dim contiguous, uniform row pitch) @ w[N, K]^T -> [..., round8(N)]."""
     _check_dev(x, w, bias, residual, out)
     lib = _lib.load()
@@ -165,6 +167,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.out = _ptr(o2)
     p.ldo = o2.stride(0) if m > 1 else max(o2.shape[-1], o2.stride(0))
     p.nb1 = p.nb2 = 1
+    p.variant = int(variant)
     _ws = _set_splitk(p, m, n, k, x) if act != ACT_GEGLU else None  # noqa: F841
     if act == ACT_GEGLU:
         p.ksplit, p.workspace = 1, None

@@ -1,0 +1,105 @@
+"""Parity of the 8-wave 256 x 320/256 GEMM variant (csrc/saspa_gemm_pp.hip) against the torch-fp32 CPU
+reference of the same op, through the C ABI (SaspaGemmParams.variant = SASPA_GEMM_WIDE pins it; the
+last tests use shapes that the library routes there by itself).  bf16 tolerance: tests/util.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from saspa_aug_amd import ops
+from saspa_aug_amd import weights as W
+from util import assert_close, from_nhwc, q, to_nhwc
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+WIDE_CONV_CASES = [
+    # (B, H, W, Cin, Cout, k, stride, upsample)
+    (2, 16, 16, 64, 96, 3, 1, False),     # one 256-row tile per image pair, N tail inside the 320-wide tile
+    (2, 16, 16, 64, 64, 3, 2, False),     # stride 2 (Downsample2D)
+    (1, 8, 12, 64, 48, 3, 1, True),       # nearest x2 + conv (Upsample2D)
+    (3, 9, 7, 64, 24, 3, 1, False),       # ragged M (189 rows), halo on every side
+    (2, 8, 8, 128, 128, 1, 1, False),     # 1x1
+    (2, 24, 24, 128, 256, 3, 1, False),   # N = 256 -> 256x256 tile; M = 1152 = 4.5 tiles
+    (1, 16, 16, 512, 320, 3, 1, False),   # K = 4608: the caller's split-K request goes through the wide kernel
+    (5, 4, 4, 64, 320, 3, 1, False),      # images of 16 pixels: a tile holds 16 images' time-embedding rows
+    (1, 40, 40, 192, 640, 3, 1, False),   # two N tiles, 6.25 M tiles, 27 K-tiles
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CONV_CASES)
+def test_wide_conv(dev, case):
+    b, h, w_, cin, cout, k, stride, up = case
+    x = q(_rand(b, cin, h, w_, seed=7), BF)
+    wt = q(_rand(cout, cin, k, k, seed=8, scale=1 / math.sqrt(cin * k * k)), BF)
+    bias = _rand(cout, seed=9)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, wt, bias, stride=stride, padding=k // 2)
+    out = ops.conv(to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF), bias.to(dev), kh=k, kw=k, stride=stride, pad=k // 2,
+                   upsample=up, variant=ops.GEMM_WIDE)
+    assert_close(from_nhwc(out, cout), ref, BF, what=f"wide conv {case}")
+
+
+@pytest.mark.parametrize("h", [4, 16])
+def test_wide_conv_concat_rowvec_residual_silu(dev, h):
+    """Up-block resnet conv1 (two sources with different pitches + time-embedding rows), conv2 (residual, alpha),
+    and the SiLU epilogue of the cond-embedding convs."""
+    b, w_, c0, c1, cout = 3, h, 128, 64, 320
+    x0, x1 = q(_rand(b, c0, h, w_, seed=10), BF), q(_rand(b, c1, h, w_, seed=11), BF)
+    wt = q(_rand(cout, c0 + c1, 3, 3, seed=12, scale=0.03), BF)
+    bias, rv = _rand(cout, seed=13), _rand(b, cout, seed=14)
+    res = q(_rand(b, cout, h, w_, seed=15), BF)
+    conv = F.conv2d(torch.cat([x0, x1], 1), wt, bias, padding=1) + rv[:, :, None, None]
+    wd = W.pack_conv_split(wt, c0, c0, c1, c1).to(dev, BF)
+    a0, a1 = to_nhwc(x0, BF, dev), to_nhwc(x1, BF, dev)
+    out = ops.conv(a0, wd, bias.to(dev), kh=3, kw=3, pad=1, x2=a1, rowvec=rv.to(dev), residual=to_nhwc(res, BF, dev), alpha=0.5,
+                   variant=ops.GEMM_WIDE)
+    assert_close(from_nhwc(out, cout), conv * 0.5 + res, BF, what="wide concat conv")
+    out = ops.conv(a0, wd, bias.to(dev), kh=3, kw=3, pad=1, x2=a1, rowvec=rv[0].to(dev), act=ops.ACT_SILU, variant=ops.GEMM_WIDE)
+    ref = F.silu(F.conv2d(torch.cat([x0, x1], 1), wt, bias, padding=1) + rv[0][None, :, None, None])
+    assert_close(from_nhwc(out, cout), ref, BF, what="wide concat conv, shared row, SiLU")
+
+
+@pytest.mark.parametrize("m,k,n", [(300, 320, 960), (77, 768, 320), (1, 320, 1280), (4096, 1280, 320), (513, 64, 8)])
+def test_wide_linear(dev, m, k, n):
+    x, wt, bias = q(_rand(m, k, seed=1), BF), q(_rand(n, k, seed=2, scale=1 / math.sqrt(k)), BF), _rand(n, seed=3)
+    res = q(_rand(m, n, seed=4), BF)
+    out = ops.linear(x.to(dev, BF), wt.to(dev, BF), bias.to(dev), residual=res.to(dev, BF), variant=ops.GEMM_WIDE)
+    assert_close(out.float().cpu(), x @ wt.t() + bias + res, BF, what=f"wide linear {m}x{k}x{n}")
+
+
+def test_wide_rejects_what_it_cannot_run(dev):
+    x = torch.zeros(2, 8, 8, 32, device=dev, dtype=BF)          # 32 channels: a K-tile would straddle taps
+    wt = torch.zeros(64, 9 * 32, device=dev, dtype=BF)
+    with pytest.raises(RuntimeError):
+        ops.conv(x, wt, kh=3, kw=3, pad=1, variant=ops.GEMM_WIDE)
+    xf = torch.zeros(64, 64, device=dev)                         # fp32 parity mode has no wide kernel
+    with pytest.raises(RuntimeError):
+        ops.linear(xf, torch.zeros(64, 64, device=dev), variant=ops.GEMM_WIDE)
+
+
+def test_auto_dispatch_level0_resnet_conv(dev):
+    """The bench shape the variant exists for (UNet level 0: 64x64 latents, 320 channels, CFG batch): AUTO and the
+    pinned 4-wave kernel must agree with the CPU reference on the first and last image (whole tensor vs each other)."""
+    b, h, w_, c = 12, 64, 64, 320
+    x = q(_rand(b, c, h, w_, seed=21), BF)
+    wt = q(_rand(c, c, 3, 3, seed=22, scale=1 / math.sqrt(9 * c)), BF)
+    bias, rv = _rand(c, seed=23), _rand(b, c, seed=24)
+    xd, wd = to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF)
+    auto = ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev))
+    wide = ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev), variant=ops.GEMM_WIDE)
+    tiled = ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev), variant=ops.GEMM_TILED)
+    assert torch.equal(auto, wide), "AUTO did not take the wide kernel for M = 49152, N = 320, K = 2880"
+    for i in (0, b - 1):
+        ref = F.conv2d(x[i:i + 1], wt, bias, padding=1) + rv[i][None, :, None, None]
+        assert_close(from_nhwc(wide[i:i + 1]), ref, BF, what=f"level-0 conv image {i} (wide)")
+        assert_close(from_nhwc(tiled[i:i + 1]), ref, BF, what=f"level-0 conv image {i} (tiled)")
+    # the two kernels sum K in the same tile order per output; they may differ by bf16 rounding only
+    assert (wide.float() - tiled.float()).abs().max().item() <= 0.0625

@@ -206,6 +206,19 @@ def main():
                     flops_per_launch_avg=round(gm["flops"] / gm["launches"] / 1e9, 3),
                     note="achieved = sum of algorithmic FLOPs (2*M*N*K) of every launch of this kernel in a 2-step "
                          "batch-8 generation / sum of their HIP-event durations")
+        # HBM traffic per launch of the same kernel family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+        # tools/pmc_step.py (the same warm + 2-step generation), corrected per MI355X_MICROARCH.md; collected offline
+        # (counters cannot be read inside this process) and committed under profiles/ by tools/pmc_traffic_json.py
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic*.json")))
+        if tfiles:
+            try:
+                tj = json.load(open(tfiles[-1]))
+                roof["traffic"] = round(tj["hbm_bytes_per_launch"])
+                roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE, PMC, avg over the kernel family)"
+                roof["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
+            except Exception:  # a malformed profile file must not take the bench line down
+                pass
         if "flash_attn" in summ:
             fa = summ["flash_attn"]
             roof["flash_attn_tflops"] = round(fa["flops"] / (fa["ms"] * 1e-3) / 1e12, 1)

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   const int abl = (ntiles_abl >> 28) & 15;
   const bool stamp = (ntiles_abl >> 27) & 1;           // block 0 leaves (shader clocks, 100 MHz ticks) of its K loop in out[0..15]
   unsigned long long st0 = 0, sr0 = 0, st1 = 0, sr1 = 0;
+  const unsigned long long sr_entry = __builtin_amdgcn_s_memrealtime();
 #else
   constexpr int abl = 0;
 #endif
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
       unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<T*>(p.out) + (long long)p.M * p.ldo) + 4 * blockIdx.x;
       o[0] = sr0;
       o[1] = sr1;
-      o[2] = st1 - st0;
+      o[2] = ((st1 - st0) << 20) | ((sr0 - sr_entry) & 0xfffff);   // loop clocks | entry -> loop start ticks
       o[3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif

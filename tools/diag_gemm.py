@@ -1,5 +1,5 @@
 import sys, math, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import saspa_aug_amd
 from saspa_aug_amd import ops
 dev = torch.device('cuda:0')

@@ -2,7 +2,7 @@
 UNet+ControlNet evaluation at the bench shape (B=8 images, CFG -> 16 samples, 512x512)."""
 import sys, collections
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import saspa_aug_amd
 from saspa_aug_amd import config as CFG, ops
 from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline

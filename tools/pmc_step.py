@@ -1,7 +1,7 @@
 """One warm + one measured 2-step generation at the bench shape (for rocprofv3 --pmc runs)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import saspa_aug_amd
 from saspa_aug_amd import config as CFG, ops
 from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline

@@ -2,7 +2,7 @@
 import os, sys, math, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
-    sys.path.insert(0, '.')
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
     import saspa_aug_amd  # noqa: F401
     from saspa_aug_amd import ops
     dev = torch.device('cuda:0')

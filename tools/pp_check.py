@@ -17,7 +17,7 @@ CONVS = [
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     import torch.nn.functional as F
-    sys.path.insert(0, '.')
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
     import saspa_aug_amd  # noqa: F401
     from saspa_aug_amd import ops, weights
     dev = torch.device('cuda:0')

@@ -2,7 +2,7 @@
 import os, sys, time
 os.environ.setdefault("SASPA_GEMM_PP", "5"); os.environ["SASPA_GEMM_STAMP"] = "1"
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
 from saspa_aug_amd import ops
 dev = torch.device('cuda:0')
@@ -17,13 +17,15 @@ while time.time() - t0 < 2.5:
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.conv(x, w, kh=3, kw=3, pad=1, out=out); e1.record(); torch.cuda.synchronize()
 st = big[16].reshape(-1).view(torch.int64)[:4 * 256].reshape(256, 4).cpu()
-s0, s1, clk, end = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+s0, s1, clk, end = st[:, 0], st[:, 1], st[:, 2] >> 20, st[:, 3]
+pre = st[:, 2] & 0xfffff
 base = s0.min()
 f = lambda t: f"min {float(t.min()) / 100:7.1f} med {float(t.median()) / 100:7.1f} max {float(t.max()) / 100:7.1f}"
 print(f"ablate={os.environ.get('SASPA_GEMM_ABLATE', '0')} event time {e0.elapsed_time(e1) * 1e3:.1f} us")
 print("loop start (us after first) :", f(s0 - base))
 print("loop end                    :", f(s1 - base))
 print("kernel end                  :", f(end - base))
+print("entry -> loop start (us)     :", f(pre))
 print("loop duration               :", f(s1 - s0))
 print("epilogue duration           :", f(end - s1))
 print(f"in-loop clock GHz: med {float((clk.float() / (s1 - s0).float()).median()) * 0.1:.3f}")

@@ -2,7 +2,7 @@ import os, sys, math, subprocess
 shapes = [(65536,320,320),(65536,320,1280),(65536,640,320),(16384,640,640),(16384,640,2560),(16384,1280,640),(4096,1280,1280),(4096,1280,5120),(4096,2560,1280),(1024,1280,1280),(1024,1280,5120),(1232,320,768),(1232,1280,768)]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
-    sys.path.insert(0, '.')
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
     import saspa_aug_amd
     from saspa_aug_amd import ops
     dev = torch.device('cuda:0')

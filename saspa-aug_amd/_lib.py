@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsaspa_hip.so")
+# SASPA_HIP_LIB: load another build of the same ABI (the `make ABLATION=1` diagnostics library of tools/pp_clock.py ...)
+LIB_PATH = os.environ.get("SASPA_HIP_LIB") or os.path.join(_HERE, "libsaspa_hip.so")
 
 SASPA_BF16, SASPA_F32 = 0, 1
 ERRORS = {-1: "SASPA_EINVAL (null pointer / bad size)", -2: "SASPA_EALIGN (16-byte alignment / channel multiple)",

@@ -1,4 +1,5 @@
 """K-loop ablation of the LDS-DMA GEMM (diagnostic): time full / no-MFMA / DMA-only / no-DMA builds."""
+import os as _os; _os.environ.setdefault("SASPA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "saspa-aug_amd", "libsaspa_hip_abl.so"))
 import os, sys, math, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch

@@ -1,4 +1,5 @@
 """Per-workgroup K-loop timeline and in-kernel clock of the ping-pong GEMM (diagnostic; needs `make ABLATION=1`)."""
+import os as _os; _os.environ.setdefault("SASPA_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "saspa-aug_amd", "libsaspa_hip_abl.so"))
 import os, sys, time
 os.environ.setdefault("SASPA_GEMM_PP", "5"); os.environ["SASPA_GEMM_STAMP"] = "1"
 import torch

@@ -153,12 +153,26 @@ int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long lo
 /* ---- elementwise ----------------------------------------------------------*/
 /* GEGLU: y[m][f] = x[m][f] * gelu_erf(x[m][F+f])   (diffusers GEGLU) */
 int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int F, void* stream);
-/* act: 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) (CLIP MLP); in/out [rows][C] */
+/* act: 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) (CLIP MLP), 4 erf-GELU (BERT / Q-Former FFN); in/out [rows][C] */
 int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
                      void* stream);
 /* CLIP embeddings: out[i][:] = tok[ids[i]][:] + pos[i % npos][:] */
 int saspa_embed_tokens(int dtype, const int* ids, int n, int npos, const void* tok, const void* pos, int C,
                        void* out, void* stream);
+/* ContextCLIPTextEmbeddings of BLIP-Diffusion (a8): ids [nseq][ntok] prompt tokens, ctx
+ * [nseq][nctx][C] subject tokens spliced in at position ctx_begin (reference: ctx_begin_pos = 2, 16 tokens,
+ * ntok = 77 - 16); out [nseq][ntok+nctx][C] = spliced token embeddings + pos[0 .. ntok+nctx). */
+int saspa_embed_tokens_ctx(int dtype, const int* ids, int nseq, int ntok, const void* ctx, int nctx, int ctx_begin,
+                           const void* tok, const void* pos, int C, void* out, void* stream);
+/* classifier-free guidance + one linear-multistep update (PNDMScheduler.step_plms with skip_prk_steps, the
+ * scheduler BlipDiffusionControlNetPipeline keeps, run_aug/run_aug.py:217), fused:
+ *   e = eu + g (ec - eu);  if store_slot >= 0: hist[store_slot] = e
+ *   m = w_cur e + sum_k w_hist[k] hist[k]   (hist slots as they were BEFORE this call's store)
+ *   x' = coef_sample * s + coef_model * m,  s = sample if non-NULL else x;  x' goes to both CFG halves of x.
+ * hist: 4 slots of nimg*hw*ldc elements; the host owns which slot holds which past output. */
+int saspa_cfg_plms_step(int dtype, const void* eps, void* x, void* hist, const void* sample, int nimg, long long hw,
+                        int C, int ldc, float guidance, int store_slot, float w_cur, const float* w_hist,
+                        float coef_sample, float coef_model, void* stream);
 /* classifier-free guidance + DDIM step (eta=0), fused; writes x_prev into both
  * CFG halves of the model-input buffer.  eps: [2*nimg][hw][ldc] (uncond first),
  * x: [2*nimg][hw][ldc]; channels c < C are live.

@@ -46,6 +46,59 @@ class DDIM:
         return a_prev ** 0.5 * x0 + direction
 
 
+class PNDM:
+    """PNDMScheduler as shipped in the SD-1.5-derived BLIP-Diffusion repo (skip_prk_steps=True, scaled_linear
+    0.00085..0.012, steps_offset=1, set_alpha_to_one=False, "leading"): ``step_plms`` restated with the
+    reference's ``ets`` list ([upstream] diffusers 0.32.2 scheduling_pndm.py, recalled)."""
+
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_train, self.steps_offset, self.init_noise_sigma = num_train, steps_offset, 1.0
+
+    def set_timesteps(self, n):
+        self.n = n
+        ratio = self.num_train // n
+        base = (np.arange(0, n) * ratio).round().astype(np.int64) + self.steps_offset
+        self.timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        self.ets, self.counter, self.cur_sample = [], 0, None
+        return self.timesteps
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+    def step(self, model_output, timestep, sample):
+        timestep = int(timestep)
+        prev_timestep = timestep - self.num_train // self.n
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + self.num_train // self.n
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev_sample = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return prev_sample
+
+
 def prepare_control(control_u8):
     """VaeImageProcessor(do_normalize=False).preprocess: u8 HWC RGB -> [1,3,H,W] in [0,1]."""
     x = torch.from_numpy(np.ascontiguousarray(control_u8)).float() / 255.0
@@ -74,6 +127,40 @@ def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents,
         x2 = torch.cat([x, x], 0)
         down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x2, int(t), ctx, cond2,
                                          conditioning_scale)
+        eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
+        eps_u, eps_c = eps2.chunk(2)
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        x = sch.step(eps, t, x)
+    img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
+    out = postprocess(img)
+    if return_latents:
+        return out, x, img
+    return out
+
+
+def build_blip_prompt(prompt, tgt_subject, prompt_strength=1.0, prompt_reps=20):
+    """BlipDiffusionControlNetPipeline._build_prompt: "a {subject} {prompt}" repeated (the prompt amplifier)."""
+    p = f"a {tgt_subject} {prompt.strip()}"
+    return ", ".join([p] * int(prompt_strength * prompt_reps))
+
+
+@torch.no_grad()
+def blip_controlnet_pipeline(weights, cfgs, ids_prompt, ids_neg, query_embeds, control_u8, latents, steps,
+                             guidance_scale=7.5, ctx_begin_pos=2, return_latents=False):
+    """BlipDiffusionControlNetPipeline.__call__ as the reference invokes it (run_aug/run_aug.py:243-250, 262-265):
+    ids_prompt int64 [1, 77-nq] (the amplified prompt, tokenised to max_length - num_query_tokens), ids_neg [1,77],
+    query_embeds fp32 [1, nq, width] (Q-Former subject tokens), ControlNet conditioning scale 1.0 (none is passed),
+    PNDM/PLMS scheduler kept.  Returns u8 [1,H,W,3]."""
+    pos = M.clip_text_forward(weights["text"], cfgs["text"], ids_prompt, query_embeds, ctx_begin_pos)
+    neg = M.clip_text_forward(weights["text"], cfgs["text"], ids_neg)
+    ctx = torch.cat([neg, pos], 0)
+    cond = prepare_control(control_u8)
+    cond2 = torch.cat([cond, cond], 0)
+    sch = PNDM()
+    x = latents.clone().float() * sch.init_noise_sigma
+    for t in sch.set_timesteps(steps):
+        x2 = torch.cat([x, x], 0)
+        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x2, int(t), ctx, cond2, 1.0)
         eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
         eps_u, eps_c = eps2.chunk(2)
         eps = eps_u + guidance_scale * (eps_c - eps_u)

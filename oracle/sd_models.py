@@ -255,10 +255,16 @@ def vae_decode(sd, cfg, z):
 # --------------------------------------------------------------------------
 # CLIP text tower (last_hidden_state after final LN; causal mask; quick-GELU)
 # --------------------------------------------------------------------------
-def clip_text_forward(sd, cfg, ids):
+def clip_text_forward(sd, cfg, ids, ctx_embeddings=None, ctx_begin_pos=2):
+    """CLIPTextModel; with ``ctx_embeddings`` [B, nctx, width] it is BLIP-Diffusion's ContextCLIPTextModel
+    ([upstream] diffusers blip_diffusion/modeling_ctx_clip.py, recalled): the subject tokens are spliced into the
+    token embeddings at ``ctx_begin_pos`` BEFORE the position embeddings (of the lengthened sequence) are added."""
     pfx = "text_model"
-    b, n = ids.shape
-    x = sd[pfx + ".embeddings.token_embedding.weight"][ids] + sd[pfx + ".embeddings.position_embedding.weight"][:n][None]
+    tok = sd[pfx + ".embeddings.token_embedding.weight"][ids]
+    if ctx_embeddings is not None:
+        tok = torch.cat([tok[:, :ctx_begin_pos], ctx_embeddings.to(tok.dtype), tok[:, ctx_begin_pos:]], dim=1)
+    b, n = tok.shape[:2]
+    x = tok + sd[pfx + ".embeddings.position_embedding.weight"][:n][None]
     mask = torch.full((n, n), float("-inf")).triu_(1)
     for i in range(cfg["layers"]):
         lp = f"{pfx}.encoder.layers.{i}"

@@ -18,6 +18,18 @@ CLIP_L = dict(vocab=49408, width=768, layers=12, heads=12, mlp=3072, max_pos=77)
 
 SD15 = dict(unet=SD15_UNET, controlnet=SD15_CONTROLNET, vae=SD15_VAE, text=CLIP_L)
 
+# Salesforce/blipdiffusion(-controlnet) : qformer/config.json (Blip2QFormerModel = CLIP-L/14 vision tower with its
+# last block dropped + BERT-base Q-Former with 16 learned queries + ProjLayer), image processor mean/std, ctx_begin_pos.
+# Values recalled from the public repo / LAVIS BlipDiffusion defaults (no network here): parity unpinned.
+BLIP2_QFORMER = dict(
+    image_size=224, patch=14, vis_width=1024, vis_layers=23, vis_heads=16, vis_mlp=4096, vis_eps=1e-5,
+    width=768, layers=12, heads=12, mlp=3072, cross_freq=1, num_query=16, vocab=30523, max_pos=512, eps=1e-12,
+    proj_hidden=3072, out_dim=768,
+)
+BLIP_IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
+BLIP_IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
+BLIP_DIFFUSION = dict(SD15, qformer=BLIP2_QFORMER, ctx_begin_pos=2)
+
 
 def tiny(width=32, ctx=64, groups=8, heads=4, vae_width=16):
     """Reduced-width family with the same topology (tests / smoke)."""
@@ -28,4 +40,7 @@ def tiny(width=32, ctx=64, groups=8, heads=4, vae_width=16):
     vae = dict(latent_channels=4, out_channels=3, block_out=(vae_width, 2 * vae_width, 4 * vae_width, 4 * vae_width),
                layers=2, groups=groups, scaling_factor=0.18215)
     text = dict(vocab=512, width=ctx, layers=2, heads=4, mlp=4 * ctx, max_pos=77)
-    return dict(unet=unet, controlnet=cn, vae=vae, text=text)
+    qformer = dict(image_size=56, patch=14, vis_width=64, vis_layers=2, vis_heads=4, vis_mlp=128, vis_eps=1e-5,
+                   width=ctx, layers=2, heads=4, mlp=2 * ctx, cross_freq=1, num_query=16, vocab=512, max_pos=32, eps=1e-12,
+                   proj_hidden=2 * ctx, out_dim=ctx)
+    return dict(unet=unet, controlnet=cn, vae=vae, text=text, qformer=qformer, ctx_begin_pos=2)

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void activation_kernel(int act, const T* x, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (act == 1) a[j] = silu_f(a[j]);
+      else if (act == 4) a[j] = 0.5f * a[j] * (1.0f + erff(a[j] * 0.70710678118654752440f));   // exact (erf) GELU: BERT / Q-Former FFN
       else a[j] = a[j] / (1.0f + expf(-1.702f * a[j]));
     }
     store8(y + row * ldy + c, a);
@@ -80,6 +81,64 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* ids, int n
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] += b[j];
     store8(out + (long long)i * C + c, a);
+  }
+}
+
+// ContextCLIPTextEmbeddings (BLIP-Diffusion): row p of sequence b is the token embedding of the prompt with
+// `nctx` subject-token embeddings spliced in at position `cbeg`, plus the position embedding of p.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_ctx_kernel(const int* ids, int nseq, int ntok, const T* ctx, int nctx, int cbeg,
+                                                               const T* tok, const T* pos, int C, T* out) {
+  const int C8 = C >> 3;
+  const int len = ntok + nctx;
+  const long long total = (long long)nseq * len * C8;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int row = (int)(it / C8);
+    const int c = (int)(it - (long long)row * C8) * 8;
+    const int b = row / len, p = row - b * len;
+    float a[8], q[8];
+    if (p >= cbeg && p < cbeg + nctx) load8(ctx + ((long long)b * nctx + (p - cbeg)) * C + c, a);
+    else load8(tok + (long long)ids[b * ntok + (p < cbeg ? p : p - nctx)] * C + c, a);
+    load8(pos + (long long)p * C + c, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += q[j];
+    store8(out + (long long)row * C + c, a);
+  }
+}
+
+// CFG + one linear multistep (PNDM / PLMS) update.  e = eu + g (ec - eu) is optionally stored in the history
+// ring; m = w_cur e + sum_k w[k] hist[k]; x' = cx * s + cm * m with s = the saved sample or x itself.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hist, const T* sample, int nimg, long long hw, int C,
+                                                       float g, int store_slot, float w_cur, float w0, float w1, float w2, float w3,
+                                                       float cx, float cm) {
+  const long long total = (long long)nimg * hw;
+  const long long half = total * 8;
+  const float w[4] = {w0, w1, w2, w3};
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    float eu[8], ec[8], sv[8], e[8], m[8], o[8];
+    load8(eps + it * 8, eu);
+    load8(eps + half + it * 8, ec);
+    load8((sample ? sample : x) + it * 8, sv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = eu[j] + g * (ec[j] - eu[j]);
+      m[j] = w_cur * e[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (w[k] != 0.f) {   // uniform
+        float h[8];
+        load8(hist + k * half + it * 8, h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] += w[k] * h[j];
+      }
+    }
+    if (store_slot >= 0) store8(hist + store_slot * half + it * 8, e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (j < C) ? (cx * sv[j] + cm * m[j]) : 0.f;
+    store8(x + it * 8, o);
+    store8(x + half + it * 8, o);
   }
 }
 
@@ -159,7 +218,7 @@ extern "C" int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, 
 
 extern "C" int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
                                 void* stream) {
-  if (!x || !y || rows <= 0 || C <= 0 || (act != 1 && act != 2)) return SASPA_EINVAL;
+  if (!x || !y || rows <= 0 || C <= 0 || (act != 1 && act != 2 && act != 4)) return SASPA_EINVAL;
   if (C % 8 || ldx % 8 || ldy % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SASPA_BF16)
@@ -181,6 +240,42 @@ extern "C" int saspa_embed_tokens(int dtype, const int* ids, int n, int npos, co
     hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3(grid_for((long long)n * (C / 8))), dim3(256), 0, s, ids, n, npos, (const bf16_t*)tok, (const bf16_t*)pos, C, (bf16_t*)out);
   else if (dtype == SASPA_F32)
     hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3(grid_for((long long)n * (C / 8))), dim3(256), 0, s, ids, n, npos, (const float*)tok, (const float*)pos, C, (float*)out);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_embed_tokens_ctx(int dtype, const int* ids, int nseq, int ntok, const void* ctx, int nctx, int ctx_begin,
+                                      const void* tok, const void* pos, int C, void* out, void* stream) {
+  if (!ids || !tok || !pos || !out || nseq <= 0 || ntok <= 0 || C <= 0 || nctx < 0) return SASPA_EINVAL;
+  if (nctx > 0 && !ctx) return SASPA_EINVAL;
+  if (ctx_begin < 0 || ctx_begin > ntok) return SASPA_ERANGE;
+  if (C % 8 || !aligned16(tok) || !aligned16(pos) || !aligned16(out) || (ctx && !aligned16(ctx))) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nseq * (ntok + nctx) * (C / 8));
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(embed_tokens_ctx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, ids, nseq, ntok, (const bf16_t*)ctx, nctx, ctx_begin, (const bf16_t*)tok, (const bf16_t*)pos, C, (bf16_t*)out);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(embed_tokens_ctx_kernel<float>, dim3(grid), dim3(256), 0, s, ids, nseq, ntok, (const float*)ctx, nctx, ctx_begin, (const float*)tok, (const float*)pos, C, (float*)out);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_cfg_plms_step(int dtype, const void* eps, void* x, void* hist, const void* sample, int nimg, long long hw,
+                                   int C, int ldc, float guidance, int store_slot, float w_cur, const float* w_hist,
+                                   float coef_sample, float coef_model, void* stream) {
+  if (!eps || !x || !hist || !w_hist || nimg <= 0 || hw <= 0 || C <= 0) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8 || store_slot < -1 || store_slot > 3) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x) || !aligned16(hist) || (sample && !aligned16(sample))) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(cfg_plms_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, (bf16_t*)hist, (const bf16_t*)sample, nimg, hw, C, guidance, store_slot, w_cur, w_hist[0], w_hist[1], w_hist[2], w_hist[3], coef_sample, coef_model);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(cfg_plms_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, (float*)hist, (const float*)sample, nimg, hw, C, guidance, store_slot, w_cur, w_hist[0], w_hist[1], w_hist[2], w_hist[3], coef_sample, coef_model);
   else
     return SASPA_EINVAL;
   SASPA_CHECK_LAUNCH();

@@ -468,12 +468,17 @@ class CLIPText:
         pk.norm("text_model.final_layer_norm")
         pk.sd = None
 
-    def forward(self, ids):
-        """ids: int [B,77] (device) -> [B,77,width]"""
+    def forward(self, ids, ctx=None, ctx_begin=2):
+        """ids: int [B,n] (device) -> [B,n,width]; with ctx [B,nctx,width] (BLIP-Diffusion subject tokens) the
+        sequence is the prompt with ctx spliced in at `ctx_begin` (ContextCLIPTextModel), n + nctx long."""
         cfg, p = self.cfg, self.p
         b, n = ids.shape
         c = cfg["width"]
-        x = ops.embed_tokens(ids, p["tok"], p["pos"], n).view(b, n, c)
+        if ctx is None:
+            x = ops.embed_tokens(ids, p["tok"], p["pos"], n).view(b, n, c)
+        else:
+            x = ops.embed_tokens_ctx(ids, ctx.to(self.dtype), ctx_begin, p["tok"], p["pos"])
+            n = x.shape[1]
         for i in range(cfg["layers"]):
             lp = f"text_model.encoder.layers.{i}"
             a = lp + ".self_attn"

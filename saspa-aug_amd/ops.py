@@ -13,6 +13,7 @@ from . import _lib
 
 ACT_NONE, ACT_SILU = 0, 1
 ACT_QUICK_GELU = 2  # saspa_activation only
+ACT_GELU = 4        # saspa_activation only: erf GELU (BERT / Q-Former)
 ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
 GEMM_AUTO, GEMM_TILED, GEMM_WIDE = 0, 1, 2   # SaspaGemmParams.variant
 
@@ -321,6 +322,39 @@ def embed_tokens(ids, tok, pos, npos):
     _lib.check(lib.saspa_embed_tokens(_dt(tok), _ptr(ids32), n, npos, _ptr(tok), _ptr(pos), c, _ptr(out), _stream()),
                "saspa_embed_tokens")
     return out
+
+
+def embed_tokens_ctx(ids, ctx, ctx_begin, tok, pos):
+    """ids [B, ntok] prompt tokens, ctx [B, nctx, C] (or None) spliced in at `ctx_begin`
+    -> [B, ntok + nctx, C] = token embeddings + position embeddings (ContextCLIPTextEmbeddings)."""
+    _check_dev(ids, ctx, tok, pos)
+    lib = _lib.load()
+    b, ntok = ids.shape
+    c = tok.shape[1]
+    nctx = 0 if ctx is None else ctx.shape[1]
+    if ctx is not None:
+        if ctx.shape[0] != b or ctx.shape[2] != c or ctx.dtype != tok.dtype:
+            raise ValueError("ctx must be [B, nctx, C] in the embedding dtype")
+        ctx = ctx.contiguous()
+    if ntok + nctx > pos.shape[0]:
+        raise ValueError("sequence longer than the position table")
+    out = torch.empty((b, ntok + nctx, c), device=tok.device, dtype=tok.dtype)
+    ids32 = ids.reshape(-1).to(torch.int32)
+    _lib.check(lib.saspa_embed_tokens_ctx(_dt(tok), _ptr(ids32), b, ntok, _ptr(ctx), nctx, int(ctx_begin), _ptr(tok), _ptr(pos), c,
+                                          _ptr(out), _stream()), "saspa_embed_tokens_ctx")
+    return out
+
+
+def cfg_plms_step(eps, x, hist, sample, nimg, hw, c, guidance, store_slot, w_cur, w_hist, coef_sample, coef_model):
+    """eps, x: [2*nimg, hw, 8]; hist: [4, nimg, hw, 8] history of CFG-combined outputs; sample: [nimg, hw, 8] or None.
+    One PNDM/PLMS update (see saspa_cfg_plms_step); updates x (both CFG halves) and hist[store_slot] in place."""
+    _check_dev(eps, x, hist, sample)
+    lib = _lib.load()
+    wh = (C.c_float * 4)(*[float(v) for v in w_hist])
+    _lib.check(lib.saspa_cfg_plms_step(_dt(x), _ptr(eps), _ptr(x), _ptr(hist), _ptr(sample), nimg, hw, c, 8, float(guidance),
+                                       int(store_slot), float(w_cur), wh, float(coef_sample), float(coef_model), _stream()),
+               "saspa_cfg_plms_step")
+    return x
 
 
 def cfg_ddim_step(eps, x, nimg, hw, c, guidance, sa_t, s1m_t, sa_p, s1m_p):

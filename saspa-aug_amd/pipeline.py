@@ -23,9 +23,9 @@ from PIL import Image
 
 from . import models, ops
 from . import weights as W
-from .config import SD15
-from .scheduler import DDIMScheduler
-from .tokenizer import make_tokenizer
+from .config import BLIP_DIFFUSION, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD, SD15
+from .scheduler import DDIMScheduler, PNDMScheduler
+from .tokenizer import make_bert_tokenizer, make_tokenizer
 
 
 class PipelineOutput:
@@ -90,9 +90,13 @@ class StableDiffusionControlNetPipeline:
         self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt)
         self.vae = models.VAEDecoder(sd["vae"], cf["vae"], device, cdt)
         self.text_encoder = models.CLIPText(sd["text"], cf["text"], device, cdt)
+        self._build_extra(sd, cf, device, cdt)
         self._neg_cache = {}
         self._state_dicts = None      # the packed device copies are the weights now; free ~5.6 GB of host fp32
         return self
+
+    def _build_extra(self, sd, cf, device, cdt):
+        pass
 
     def upcast_vae(self):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
         return self
@@ -121,10 +125,47 @@ class StableDiffusionControlNetPipeline:
         x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1]))
         return (x * self.scheduler.init_noise_sigma).to(self.device, self.dtype).contiguous()
 
+    def _positive_context(self, prompt_ids, query_embeds=None):
+        return self.encode_prompts(prompt_ids)
+
+    def _sample(self, x2, b, hw, ctx, cemb2, steps, guidance_scale, cscale):
+        """The denoising loop on the CFG-doubled latents x2 [2B,h,w,8] (in place)."""
+        sch = self.scheduler
+        nc = self.cfgs["unet"]["out_channels"]
+        self.unet.prepare_context(ctx)
+        self.controlnet.prepare_context(ctx)
+        eps = torch.zeros_like(x2)
+
+        def evaluate(i):
+            mid, skips = self.unet.encode(x2, i)
+            skips2, mid2 = self.controlnet.forward(x2, i, cemb2, cscale, skips, mid)
+            self.unet.decode(mid2, skips2, i, out=eps)
+
+        if isinstance(sch, PNDMScheduler):
+            plan = sch.plan(steps)                     # N+1 evaluations, the second timestep twice
+            ts = [t for t, _ in plan]
+            self.unet.prepare_timesteps(ts)
+            self.controlnet.prepare_timesteps(ts)
+            hist = torch.zeros((4,) + tuple(x2[:b].shape), device=x2.device, dtype=x2.dtype)
+            saved = None
+            for i, (t, d) in enumerate(plan):
+                if d["save_sample"]:
+                    saved = x2[:b].clone()
+                evaluate(i)
+                ops.cfg_plms_step(eps, x2, hist, saved if d["use_saved"] else None, b, hw, nc, guidance_scale,
+                                  d["store_slot"], d["w_cur"], d["w_hist"], d["coef_sample"], d["coef_model"])
+        else:
+            ts = sch.set_timesteps(steps)
+            self.unet.prepare_timesteps(ts)
+            self.controlnet.prepare_timesteps(ts)
+            for i, t in enumerate(ts):
+                evaluate(i)
+                ops.cfg_ddim_step(eps, x2, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
+
     @torch.no_grad()
     def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps,
                        guidance_scale=7.5, controlnet_conditioning_scale=0.75, return_latents=False,
-                       latents_on_device=False):
+                       latents_on_device=False, query_embeds=None):
         """prompt_ids [B,77], negative_ids [1,77] or [B,77], control_u8 u8 [B,H,W,3] (numpy or
         device tensor), latents [B,4,H/8,W/8] noise (or, with latents_on_device, the
         channels-last [B,H/8,W/8,8] device tensor from `latents_to_device`).
@@ -141,29 +182,20 @@ class StableDiffusionControlNetPipeline:
         want = (b, hh // 8, ww // 8, 8) if latents_on_device else (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
         if tuple(latents.shape) != want:
             raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")
-        pos = self.encode_prompts(prompt_ids)
+        pos = self._positive_context(prompt_ids, query_embeds)
         neg = self._negative_context(negative_ids)
         if neg.shape[0] == 1 and b > 1:
             neg = neg.expand(b, -1, -1)
+        if neg.shape[1] != pos.shape[1]:
+            raise ValueError(f"negative context has {neg.shape[1]} tokens, positive {pos.shape[1]}")
         ctx = torch.cat([neg, pos], 0).contiguous()                       # [2B,77,C]: uncond first
         cond = ops.u8_to_act(ctrl, dt)
         cemb = self.controlnet.cond_embedding(cond)
         cemb2 = torch.cat([cemb, cemb], 0)
-        self.unet.prepare_context(ctx)
-        self.controlnet.prepare_context(ctx)
-        ts = self.scheduler.set_timesteps(num_inference_steps)
-        self.unet.prepare_timesteps(ts)
-        self.controlnet.prepare_timesteps(ts)
         x = latents if latents_on_device else self.latents_to_device(latents)
         x2 = torch.cat([x, x], 0).contiguous()
         h8, w8 = hh // 8, ww // 8
-        eps = torch.zeros_like(x2)
-        for i, t in enumerate(ts):
-            mid, skips = self.unet.encode(x2, i)
-            skips2, mid2 = self.controlnet.forward(x2, i, cemb2, controlnet_conditioning_scale, skips, mid)
-            self.unet.decode(mid2, skips2, i, out=eps)
-            ops.cfg_ddim_step(eps, x2, b, h8 * w8, self.cfgs["unet"]["out_channels"], guidance_scale,
-                              *self.scheduler.step_coefficients(t))
+        self._sample(x2, b, h8 * w8, ctx, cemb2, num_inference_steps, guidance_scale, controlnet_conditioning_scale)
         z = ops.scale(x2[:b], 1.0 / self.cfgs["vae"]["scaling_factor"])
         img = self.vae.decode(z)
         out = ops.act_to_u8(img)
@@ -191,3 +223,98 @@ class StableDiffusionControlNetPipeline:
                                   controlnet_conditioning_scale)
         arr = out.cpu().numpy()
         return PipelineOutput([Image.fromarray(a) for a in arr], [False] * len(arr))
+
+
+class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
+    """Drop-in for diffusers' `BlipDiffusionControlNetPipeline` as the reference builds and calls it for every dataset
+    but planes (run_aug/run_aug.py:181, :211, :243-250, :262-265, :521):
+
+        pipe = BlipDiffusionControlNetPipeline.from_pretrained("Salesforce/blipdiffusion-controlnet").to(DEVICE, fp16)
+        image = pipe(prompt=..., reference_image=<PIL same-class image>, condtioning_image=<canny PIL>,
+                     source_subject_category="bird", target_subject_category="bird", height=H, width=W,
+                     neg_prompt=..., num_inference_steps=..., generator=..., guidance_scale=7.5).images[0]
+
+    Differences from the SD-1.5 pipeline, all mirrored: the PNDM / PLMS scheduler of the checkpoint is kept (N+1
+    network evaluations), no ControlNet conditioning scale is passed (= 1.0), the prompt is rewritten
+    "a {category} {prompt}" and repeated prompt_strength * prompt_reps (= 20) times, tokenised to 77 - 16 tokens,
+    and the 16 subject tokens of the Q-Former front-end (saspa_aug_amd.blip.Blip2QFormer) are spliced into the
+    CLIP token embeddings at position 2.  UNet / ControlNet / VAE are the SD-1.5 architectures (shared kernels)."""
+
+    def __init__(self, state_dicts, cfgs=BLIP_DIFFUSION, tokenizer=None, scheduler=None, qformer_tokenizer=None):
+        super().__init__(state_dicts, cfgs, tokenizer, scheduler or PNDMScheduler())
+        self.qformer_tokenizer = qformer_tokenizer or make_bert_tokenizer(vocab=cfgs["qformer"]["vocab"])
+        self.qformer = None
+
+    @classmethod
+    def from_synthetic(cls, cfgs=BLIP_DIFFUSION, seed=0):
+        return cls(W.synth_family(cfgs, seed), cfgs)
+
+    @classmethod
+    def from_pretrained(cls, repo_dir, cfgs=BLIP_DIFFUSION):
+        """Local copy of Salesforce/blipdiffusion-controlnet: unet/ vae/ text_encoder/ controlnet/ qformer/ tokenizer/."""
+        def f(sub, *names):
+            for n in names:
+                p = os.path.join(repo_dir, sub, n)
+                if os.path.exists(p):
+                    return W.load_safetensors(p)
+            raise FileNotFoundError(f"no safetensors weights in {os.path.join(repo_dir, sub)}")
+        names = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "model.safetensors")
+        sds = dict(unet=f("unet", *names), vae=f("vae", *names), text=f("text_encoder", *names),
+                   controlnet=f("controlnet", *names), qformer=f("qformer", *names))
+        return cls(sds, cfgs, tokenizer=make_tokenizer(os.path.join(repo_dir, "tokenizer"), cfgs["text"]["vocab"]),
+                   qformer_tokenizer=make_bert_tokenizer(os.path.join(repo_dir, "qformer"), cfgs["qformer"]["vocab"]))
+
+    def _build_extra(self, sd, cf, device, cdt):
+        from .blip import Blip2QFormer
+        self.qformer = Blip2QFormer(sd["qformer"], cf["qformer"], device, cdt)
+
+    # ---- pieces ------------------------------------------------------------------------
+    @staticmethod
+    def build_prompt(prompt, tgt_subject, prompt_strength=1.0, prompt_reps=20):
+        p = f"a {tgt_subject} {str(prompt).strip()}"
+        return ", ".join([p] * int(prompt_strength * prompt_reps))
+
+    def prompt_token_count(self):
+        return self.cfgs["text"]["max_pos"] - self.cfgs["qformer"]["num_query"]
+
+    def get_query_embeddings(self, reference_images, source_subject_categories):
+        """reference images (PIL / u8 HWC) + category strings -> [B, 16, width] subject tokens (device)."""
+        self._need_device()
+        from .blip import preprocess_reference
+        qc = self.cfgs["qformer"]
+        px = torch.stack([preprocess_reference(im, qc, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD) for im in reference_images])
+        ids = [self.qformer_tokenizer(c) for c in source_subject_categories]
+        if len({i.shape[1] for i in ids}) == 1:
+            return self.qformer.forward(px, np.concatenate(ids))
+        # categories of different token counts: no padding mask in the kernels -> one item at a time
+        return torch.cat([self.qformer.forward(px[i:i + 1], ids[i]) for i in range(len(ids))], 0)
+
+    def _positive_context(self, prompt_ids, query_embeds=None):
+        if query_embeds is None:
+            raise ValueError("BLIP-Diffusion needs the subject tokens (query_embeds); see get_query_embeddings")
+        ids = torch.as_tensor(np.asarray(prompt_ids)) if not torch.is_tensor(prompt_ids) else prompt_ids
+        if ids.shape[1] != self.prompt_token_count():
+            raise ValueError(f"prompt must be tokenised to {self.prompt_token_count()} tokens (77 - subject tokens)")
+        return self.text_encoder.forward(ids.to(self.device), query_embeds, self.cfgs["ctx_begin_pos"])
+
+    # ---- the reference's call form (keyword names as diffusers spells them, typo included) ----
+    def __call__(self, prompt=None, reference_image=None, condtioning_image=None, source_subject_category=None,
+                 target_subject_category=None, height=512, width=512, neg_prompt="", num_inference_steps=50,
+                 generator=None, guidance_scale=7.5, prompt_strength=1.0, prompt_reps=20, **unused):
+        self._need_device()
+        if prompt is None or reference_image is None or condtioning_image is None:
+            raise ValueError("`prompt`, `reference_image` and `condtioning_image` are required")
+        ctrl = condtioning_image.convert("RGB") if isinstance(condtioning_image, Image.Image) else Image.fromarray(np.asarray(condtioning_image))
+        if ctrl.size != (width, height):        # prepare_control_image resizes the control image to (width, height)
+            ctrl = ctrl.resize((width, height), resample=Image.LANCZOS)
+        ctrl = np.asarray(ctrl, dtype=np.uint8)
+        if generator is not None and generator.device.type != "cpu":
+            raise NotImplementedError("the reference passes the global CPU generator (run_aug/run_aug.py:324)")
+        lat = torch.randn((1, self.cfgs["unet"]["in_channels"], height // 8, width // 8), generator=generator, dtype=self.noise_dtype)
+        text = self.build_prompt(prompt, target_subject_category, prompt_strength, prompt_reps)
+        ids = self.tokenizer(text, max_len=self.prompt_token_count())
+        neg = self.tokenizer(neg_prompt or "")
+        q = self.get_query_embeddings([reference_image], [source_subject_category])
+        out = self.generate_batch(ids, neg, ctrl[None], lat, num_inference_steps, guidance_scale, 1.0, query_embeds=q)
+        arr = out.cpu().numpy()
+        return PipelineOutput([Image.fromarray(a) for a in arr], None)

@@ -22,10 +22,11 @@ class HashTokenizer:
         self.vocab, self.max_len = vocab, max_len
         self.bos, self.eos = vocab - 2, vocab - 1
 
-    def __call__(self, text):
+    def __call__(self, text, max_len=None):
+        max_len = max_len or self.max_len
         words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", (text or "").lower())
-        ids = [self.bos] + [zlib.crc32(w.encode()) % (self.vocab - 2) for w in words][: self.max_len - 2] + [self.eos]
-        ids += [self.eos] * (self.max_len - len(ids))
+        ids = [self.bos] + [zlib.crc32(w.encode()) % (self.vocab - 2) for w in words][: max_len - 2] + [self.eos]
+        ids += [self.eos] * (max_len - len(ids))
         return np.asarray(ids, np.int64)[None]
 
 
@@ -77,14 +78,15 @@ class CLIPBPETokenizer:
         self.cache[token] = word
         return word
 
-    def __call__(self, text):
+    def __call__(self, text, max_len=None):
+        max_len = max_len or self.max_len
         text = re.sub(r"\s+", " ", (text or "")).strip().lower()
         ids = []
         for tok in re.findall(self.pat, text):
             tok = "".join(self.byte_enc[b] for b in tok.encode("utf-8"))
             ids += [self.encoder[p] for p in self._bpe(tok)]
-        ids = [self.bos] + ids[: self.max_len - 2] + [self.eos]
-        ids += [self.eos] * (self.max_len - len(ids))
+        ids = [self.bos] + ids[: max_len - 2] + [self.eos]
+        ids += [self.eos] * (max_len - len(ids))
         return np.asarray(ids, np.int64)[None]
 
 
@@ -92,3 +94,55 @@ def make_tokenizer(vocab_dir=None, vocab=49408):
     if vocab_dir and os.path.exists(os.path.join(vocab_dir, "vocab.json")):
         return CLIPBPETokenizer(vocab_dir)
     return HashTokenizer(vocab)
+
+
+# ---- BERT tokenizer of the BLIP-Diffusion Q-Former (subject category text, e.g. "bird") ----------------------
+class BertHashTokenizer:
+    """Stand-in for synthetic-weight runs ([CLS] words [SEP], no padding); NOT the bert-base-uncased vocabulary."""
+
+    def __init__(self, vocab=30523):
+        self.vocab = vocab
+        self.cls, self.sep = (101, 102) if vocab > 1000 else (1, 2)
+
+    def __call__(self, text):
+        words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", (text or "").lower())
+        lo = 1000 if self.vocab > 2000 else 3
+        return np.asarray([self.cls] + [lo + zlib.crc32(w.encode()) % (self.vocab - lo) for w in words] + [self.sep], np.int64)[None]
+
+
+class BertWordPieceTokenizer:
+    """bert-base-uncased WordPiece from the checkpoint's vocab.txt (lower-case, punctuation split, greedy
+    longest-match-first with ## continuation pieces)."""
+
+    def __init__(self, vocab_file):
+        with open(vocab_file, encoding="utf-8") as f:
+            self.vocab = {tok.rstrip("\n"): i for i, tok in enumerate(f)}
+        self.cls, self.sep, self.unk = self.vocab["[CLS]"], self.vocab["[SEP]"], self.vocab["[UNK]"]
+
+    def _pieces(self, word):
+        out, start = [], 0
+        while start < len(word):
+            end, cur = len(word), None
+            while start < end:
+                sub = ("##" if start else "") + word[start:end]
+                if sub in self.vocab:
+                    cur = self.vocab[sub]
+                    break
+                end -= 1
+            if cur is None:
+                return [self.unk]
+            out.append(cur)
+            start = end
+        return out
+
+    def __call__(self, text):
+        ids = [self.cls]
+        for w in re.findall(r"[a-z0-9]+|[^\sa-z0-9]", (text or "").lower()):
+            ids += self._pieces(w)
+        return np.asarray(ids + [self.sep], np.int64)[None]
+
+
+def make_bert_tokenizer(vocab_dir=None, vocab=30523):
+    if vocab_dir and os.path.exists(os.path.join(vocab_dir, "vocab.txt")):
+        return BertWordPieceTokenizer(os.path.join(vocab_dir, "vocab.txt"))
+    return BertHashTokenizer(vocab)

@@ -149,7 +149,55 @@ def clip_text_spec(cfg):
     return spec
 
 
-SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec)
+def blip2_qformer_spec(cfg):
+    """Blip2QFormerModel of the BLIP-Diffusion repos (diffusers pipelines/blip_diffusion/modeling_blip2.py key names,
+    recalled): vision tower, learned queries, BERT embeddings / layers with per-layer cross-attention and separate
+    query / text feed-forwards, ProjLayer."""
+    vw, w = cfg["vis_width"], cfg["width"]
+    npos = (cfg["image_size"] // cfg["patch"]) ** 2 + 1
+    v = "visual_encoder"
+    spec = [(v + ".embeddings.class_embedding", (1, 1, vw), "embed"),
+            (v + ".embeddings.patch_embedding.weight", (vw, 3, cfg["patch"], cfg["patch"]), "w"),
+            (v + ".embeddings.position_embedding", (1, npos, vw), "embed"),
+            (v + ".pre_layernorm.weight", (vw,), "gain"), (v + ".pre_layernorm.bias", (vw,), "bias")]
+    for i in range(cfg["vis_layers"]):
+        lp = f"{v}.encoder.layers.{i}"
+        spec += [(lp + ".layer_norm1.weight", (vw,), "gain"), (lp + ".layer_norm1.bias", (vw,), "bias"),
+                 (lp + ".self_attn.qkv.weight", (3 * vw, vw), "w"), (lp + ".self_attn.qkv.bias", (3 * vw,), "bias"),
+                 (lp + ".self_attn.projection.weight", (vw, vw), "w"), (lp + ".self_attn.projection.bias", (vw,), "bias"),
+                 (lp + ".layer_norm2.weight", (vw,), "gain"), (lp + ".layer_norm2.bias", (vw,), "bias"),
+                 (lp + ".mlp.fc1.weight", (cfg["vis_mlp"], vw), "w"), (lp + ".mlp.fc1.bias", (cfg["vis_mlp"],), "bias"),
+                 (lp + ".mlp.fc2.weight", (vw, cfg["vis_mlp"]), "w"), (lp + ".mlp.fc2.bias", (vw,), "bias")]
+    spec += [(v + ".post_layernorm.weight", (vw,), "gain"), (v + ".post_layernorm.bias", (vw,), "bias"),
+             ("query_tokens", (1, cfg["num_query"], w), "embed"),
+             ("embeddings.word_embeddings.weight", (cfg["vocab"], w), "embed"),
+             ("embeddings.position_embeddings.weight", (cfg["max_pos"], w), "embed"),
+             ("embeddings.LayerNorm.weight", (w,), "gain"), ("embeddings.LayerNorm.bias", (w,), "bias")]
+
+    def dense_ln(pfx, cin, cout):
+        return [(pfx + ".dense.weight", (cout, cin), "w"), (pfx + ".dense.bias", (cout,), "bias"),
+                (pfx + ".LayerNorm.weight", (cout,), "gain"), (pfx + ".LayerNorm.bias", (cout,), "bias")]
+
+    for i in range(cfg["layers"]):
+        lp = f"encoder.layer.{i}"
+        for n in ("query", "key", "value"):
+            spec += [(f"{lp}.attention.attention.{n}.weight", (w, w), "w"), (f"{lp}.attention.attention.{n}.bias", (w,), "bias")]
+        spec += dense_ln(lp + ".attention.output", w, w)
+        if i % cfg["cross_freq"] == 0:
+            spec += [(f"{lp}.crossattention.attention.query.weight", (w, w), "w"), (f"{lp}.crossattention.attention.query.bias", (w,), "bias")]
+            for n in ("key", "value"):
+                spec += [(f"{lp}.crossattention.attention.{n}.weight", (w, vw), "w"), (f"{lp}.crossattention.attention.{n}.bias", (w,), "bias")]
+            spec += dense_ln(lp + ".crossattention.output", w, w)
+        for sfx in ("", "_query"):
+            spec += [(f"{lp}.intermediate{sfx}.dense.weight", (cfg["mlp"], w), "w"), (f"{lp}.intermediate{sfx}.dense.bias", (cfg["mlp"],), "bias")]
+            spec += dense_ln(f"{lp}.output{sfx}", cfg["mlp"], w)
+    spec += [("proj_layer.dense1.weight", (cfg["proj_hidden"], w), "w"), ("proj_layer.dense1.bias", (cfg["proj_hidden"],), "bias"),
+             ("proj_layer.dense2.weight", (cfg["out_dim"], cfg["proj_hidden"]), "w"), ("proj_layer.dense2.bias", (cfg["out_dim"],), "bias"),
+             ("proj_layer.LayerNorm.weight", (w,), "gain"), ("proj_layer.LayerNorm.bias", (w,), "bias")]
+    return spec
+
+
+SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec, qformer=blip2_qformer_spec)
 
 
 def synth_state_dict(kind, cfg, seed=0):
@@ -173,7 +221,8 @@ def synth_state_dict(kind, cfg, seed=0):
 
 
 def synth_family(cfgs, seed=0):
-    return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(("unet", "controlnet", "vae", "text"))}
+    kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ())
+    return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
 
 
 def load_safetensors(path):

@@ -1,0 +1,165 @@
+"""GPU parity of the BLIP-Diffusion additions against the CPU oracle on identical seeded weights /
+inputs: the fused CFG + PLMS update, the context CLIP text encoder, the Q-Former subject front-end and the whole
+`BlipDiffusionControlNetPipeline` sampling loop.  fp32 path: north-star bar (atol 1e-3 per pixel, <= 1 u8 level);
+bf16 path: reported, bounded loosely."""
+import numpy as np
+import pytest
+import torch
+
+import saspa_aug_amd  # noqa: F401
+from oracle import blip_models as OB
+from oracle import pipeline as OP
+from oracle import sd_models as OM
+from saspa_aug_amd import config as CFG
+from saspa_aug_amd import models, ops
+from saspa_aug_amd import weights as W
+from saspa_aug_amd.blip import Blip2QFormer, preprocess_reference
+from saspa_aug_amd.pipeline import BlipDiffusionControlNetPipeline
+from saspa_aug_amd.scheduler import PNDMScheduler
+from saspa_aug_amd.synthetic import synthetic_image
+from tests.util import from_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfgs = CFG.tiny()
+    return cfgs, W.synth_family(cfgs, seed=3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("steps", [1, 2, 5, 12])
+def test_cfg_plms_step_matches_pndm(dev, dtype, steps):
+    """The host plan + saspa_cfg_plms_step reproduce PNDMScheduler.step_plms (counter / ets logic, N+1 evaluations)."""
+    n, hw, c = 2, 24, 4
+    g = torch.Generator().manual_seed(steps)
+    x0 = torch.randn(n, hw, 8, generator=g); x0[..., c:] = 0
+    sch_o = OP.PNDM()
+    ts = sch_o.set_timesteps(steps)
+    plan = PNDMScheduler().plan(steps)
+    assert [t for t, _ in plan] == [int(t) for t in ts]
+    x2 = torch.cat([x0, x0]).to(dev, dtype).contiguous()
+    hist = torch.zeros((4, n, hw, 8), device=dev, dtype=dtype)
+    saved, xr, gs = None, x0.to(dtype).float(), 7.5
+    for (t, d), tt in zip(plan, ts):
+        eps = torch.randn(2 * n, hw, 8, generator=g).to(dtype)
+        eps[..., c:] = 0
+        eu, ec = eps.float().chunk(2)
+        xr = sch_o.step(eu + gs * (ec - eu), tt, xr)
+        if d["save_sample"]:
+            saved = x2[:n].clone()
+        ops.cfg_plms_step(eps.to(dev), x2, hist, saved if d["use_saved"] else None, n, hw, c, gs, d["store_slot"], d["w_cur"],
+                          d["w_hist"], d["coef_sample"], d["coef_model"])
+        assert torch.equal(x2[:n], x2[n:])
+    err = ((x2[:n].float().cpu() - xr).abs().max() / xr.abs().max()).item()
+    assert err < (1e-5 if dtype == torch.float32 else 3e-2), err       # bf16: state and history are re-rounded every step
+    assert x2[..., c:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_context_clip_text(dev, tiny, dtype):
+    """ContextCLIPTextModel: 16 subject tokens spliced in at position 2 of a 61-token prompt; plain form unchanged."""
+    cfgs, fam = tiny
+    tc = cfgs["text"]
+    ids = torch.from_numpy(np.random.RandomState(5).randint(0, tc["vocab"] - 2, (3, 61)))
+    ctx = torch.randn(3, 16, tc["width"], generator=torch.Generator().manual_seed(6))
+    ref = OM.clip_text_forward(fam["text"], tc, ids, ctx, 2)
+    enc = models.CLIPText(dict(fam["text"]), tc, dev, dtype)
+    got = enc.forward(ids.to(dev), ctx.to(dev, dtype), 2)
+    assert got.shape == (3, 77, tc["width"])
+    rel = ((got.float().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert rel < (2e-4 if dtype == torch.float32 else 6e-2), rel
+    ids77 = torch.from_numpy(np.random.RandomState(7).randint(0, tc["vocab"] - 2, (2, 77)))
+    rel = ((enc.forward(ids77.to(dev)).float().cpu() - OM.clip_text_forward(fam["text"], tc, ids77)).abs().max()).item()
+    assert rel < (2e-4 if dtype == torch.float32 else 0.15), rel
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qformer_front_end(dev, tiny, dtype):
+    cfgs, fam = tiny
+    qc = cfgs["qformer"]
+    imgs = [synthetic_image(96, 80, 40 + i) for i in range(2)]
+    px = torch.stack([preprocess_reference(im, qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD) for im in imgs])
+    assert torch.equal(px[0:1], OB.preprocess_reference(imgs[0], qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD))
+    ids = torch.tensor([[1, 17, 2], [1, 300, 2]])
+    ref = OB.blip2_qformer_forward(fam["qformer"], qc, px, ids)
+    qf = Blip2QFormer(dict(fam["qformer"]), qc, dev, dtype)
+    vis = qf.vision(px)
+    vref = OB.blip2_vision_forward(fam["qformer"], qc, px)
+    rel_v = ((vis.float().cpu() - vref).abs().max() / vref.abs().max()).item()
+    got = qf.forward(px, ids)
+    rel = ((got.float().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert rel_v < (2e-4 if dtype == torch.float32 else 6e-2), rel_v
+    assert rel < (3e-4 if dtype == torch.float32 else 8e-2), rel
+
+
+def test_qformer_full_width_fp32(dev):
+    """Real widths (CLIP-L/14 tower with 23 blocks + BERT-base Q-Former, 494 M parameters), one image."""
+    qc = CFG.BLIP2_QFORMER
+    sd = W.synth_state_dict("qformer", qc, 11)
+    px = preprocess_reference(synthetic_image(300, 260, 77), qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD)[None]
+    ids = torch.tensor([[101, 4743, 102]])
+    ref = OB.blip2_qformer_forward(sd, qc, px, ids)
+    got = Blip2QFormer(sd, qc, dev, torch.float32).forward(px, ids)
+    rel = ((got.float().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert got.shape == (1, 16, 768) and rel < 5e-4, rel
+
+
+def _blip_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg=2):
+    from oracle.canny import generate_canny_array
+    nt = cfgs["text"]["max_pos"] - cfgs["qformer"]["num_query"]
+    ids = torch.from_numpy(np.random.RandomState(1).randint(0, cfgs["text"]["vocab"] - 2, (nimg, nt)))
+    neg = torch.from_numpy(np.random.RandomState(2).randint(0, cfgs["text"]["vocab"] - 2, (1, 77)))
+    ctrls = np.stack([generate_canny_array(synthetic_image(hh, ww, 10 + i), 120, 200) for i in range(nimg)])
+    subj = [synthetic_image(80, 72, 30 + i) for i in range(nimg)]
+    cat_ids = torch.tensor([[1, 9, 2]] * nimg)
+    g = torch.manual_seed(1)
+    lat = torch.cat([torch.randn((1, 4, hh // 8, ww // 8), generator=g, dtype=torch.float32) for _ in range(nimg)])
+    qc = cfgs["qformer"]
+    refs = []
+    for i in range(nimg):
+        px = OB.preprocess_reference(subj[i], qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD)
+        q = OB.blip2_qformer_forward(fam["qformer"], qc, px, cat_ids[i:i + 1])
+        refs.append(OP.blip_controlnet_pipeline(fam, cfgs, ids[i:i + 1], neg, q, ctrls[i], lat[i:i + 1], steps, return_latents=True))
+    pipe = BlipDiffusionControlNetPipeline(dict(fam), cfgs).to(dev, dtype)
+    px = torch.stack([preprocess_reference(s, qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD) for s in subj])
+    q = pipe.qformer.forward(px, cat_ids)
+    out, x, img = pipe.generate_batch(ids.numpy(), neg.numpy(), ctrls, lat, steps, 7.5, 1.0, return_latents=True, query_embeds=q)
+    ref_u8 = np.concatenate([r[0] for r in refs])
+    ref_img = torch.cat([r[2] for r in refs])
+    got_img = from_nhwc(img, 3)
+    d01 = ((got_img / 2 + 0.5).clamp(0, 1) - (ref_img / 2 + 0.5).clamp(0, 1)).abs().max().item()
+    du8 = int(np.abs(out.cpu().numpy().astype(int) - ref_u8.astype(int)).max())
+    mse = float(((got_img / 2 + 0.5).clamp(0, 1) - (ref_img / 2 + 0.5).clamp(0, 1)).pow(2).mean())
+    return d01, du8, 10 * np.log10(1.0 / max(mse, 1e-20))
+
+
+def test_blip_pipeline_fp32_parity_tiny(dev, tiny):
+    """Whole config-3 path (Q-Former -> context CLIP -> 8-step PLMS = 9 UNet+ControlNet evaluations -> VAE), fp32."""
+    cfgs, fam = tiny
+    d01, du8, psnr = _blip_case(cfgs, fam, dev, torch.float32, 64, 64, 8)
+    assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)
+
+
+def test_blip_pipeline_bf16_tiny(dev, tiny):
+    cfgs, fam = tiny
+    d01, du8, psnr = _blip_case(cfgs, fam, dev, torch.bfloat16, 64, 64, 8)
+    print(f"bf16 8-step tiny BLIP pipeline: max|d|={d01:.4f} (u8 {du8}) PSNR={psnr:.1f} dB")
+    assert psnr > 22.0, (d01, du8, psnr)
+
+
+def test_blip_call_form(dev, tiny):
+    """The reference's call form (run_aug/run_aug.py:243-250, 262-265), keyword spelling included."""
+    from PIL import Image
+    cfgs, fam = tiny
+    pipe = BlipDiffusionControlNetPipeline(dict(fam), cfgs).to("cuda:0", torch.float16)
+    ctrl = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    subject = Image.fromarray(synthetic_image(120, 90, 3))
+    kw = dict(prompt="a bird perched on a mossy branch", reference_image=subject, condtioning_image=ctrl,
+              source_subject_category="bird", target_subject_category="bird", height=64, width=96, neg_prompt="blurry",
+              num_inference_steps=3, guidance_scale=7.5)
+    a = pipe(generator=torch.manual_seed(1), **kw).images[0]
+    b = pipe(generator=torch.manual_seed(1), **kw).images[0]
+    assert a.size == (96, 64) and a.mode == "RGB" and np.array_equal(np.asarray(a), np.asarray(b))
+    assert pipe.build_prompt("on a branch.", "bird", 1.0, 2) == "a bird on a branch., a bird on a branch."

@@ -6,7 +6,7 @@ the reference's run_aug/run_aug.py:513-556) and run
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_aug/run_aug.py   # 8 MI355X
 
 Environment overlays (optional): SASPA_DATASET, SASPA_WEIGHTS_DIR, SASPA_PROMPTS_FILE,
-SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION."""
+SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION, SASPA_BASE_MODEL (sd_v1.5 | blip_diffusion)."""
 import os
 import sys
 from pathlib import Path
@@ -23,7 +23,7 @@ if __name__ == "__main__":
     DEVICE = "cuda:0"
     version = "v1"
     DATASET = os.environ.get("SASPA_DATASET", "planes")
-    BASE_MODEL = "sd_v1.5"
+    BASE_MODEL = os.environ.get("SASPA_BASE_MODEL") or ("sd_v1.5" if DATASET in ("planes", "synthetic") else "blip_diffusion")
     CONTROLNET = "canny"
     SDEDIT = 0
     NUM_PER_IMAGE = int(os.environ.get("SASPA_NUM_PER_IMAGE", 2))

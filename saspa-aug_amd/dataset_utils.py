@@ -41,7 +41,7 @@ class BaseUtils:
         stem = Path(image_path).stem
         cls = self.image_path_to_class_str_dict[stem]
         same = [p for p, c in self.image_path_to_class_str_dict.items() if c == cls]
-        return [str(self.images_path / f"{p}.jpg") for p in same]
+        return [str(self.images_path / f"{p}{getattr(self, 'image_ext', '.jpg')}") for p in same]
 
 
 class PlanesUtils(BaseUtils):
@@ -53,6 +53,7 @@ class PlanesUtils(BaseUtils):
         super().__init__(split, root_path, print_func=print_func)
         self.name = "planes"
         self.meta_class = "airplane"
+        self.image_ext = image_ext
         self.images_path = Path(root_path) / "images"
         self.images_folder = self.root_path / "images"
         self.txt_file_path = self.root_path / f"images_{split}.txt"

@@ -77,6 +77,7 @@ class Settings:
     CONTROLNET_CONDITIONING_SCALE: float = 0.75
     SEMANTIC_FILTERING: int = 1
     MODEL_CONFIDENCE_BASED_FILTERING: int = 1
+    STYLE_IMG_FROM_DIFF_IMG: bool = True   # blip_diffusion: subject image = another image of the same class (:548)
     # additions of this build
     BATCH_SIZE: int = 8
     PRECISION: str = "bf16"            # "bf16" (production) | "fp32" (parity mode)
@@ -97,6 +98,7 @@ class WorkItem:
     height: int
     width: int
     noise_offset: int = -1   # element offset into the sequential fp16/fp32 CPU noise stream
+    subject_path: str = None # BLIP-Diffusion: the same-class image whose subject is injected (run_aug/run_aug.py:446)
     skip: bool = False
     status: int = 0       # 0 skipped (exists), 1 generated, -1 failed
 
@@ -112,7 +114,7 @@ def prompt_str_for(s: Settings):
         p += f"_artistic_prompts_p_{s.ARTISTIC_PROMPTS_PROB}"
     if s.USE_CAMERA_VARIATIONS_PROMPTS:
         p += f"_camera_variations_p_{s.CAMERA_VAIRATIONS_PROB}"
-    if "blip_diffusion" in s.BASE_MODEL:
+    if "blip_diffusion" in s.BASE_MODEL and s.STYLE_IMG_FROM_DIFF_IMG:
         p += "_style_img_from_diff_img"
     return p
 
@@ -141,16 +143,26 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
     SaSPA configuration for planes and the BASELINE metric).  `use_compile` is accepted and
     ignored: the reference's torch.compile(reduce-overhead) has no counterpart, the kernels are
     launched directly."""
-    from .config import SD15
-    from .pipeline import StableDiffusionControlNetPipeline
+    from .config import BLIP_DIFFUSION, SD15
+    from .pipeline import BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline
     from .scheduler import DDIMScheduler
     assert base_model in BASE_MODEL_DICT.keys()
     assert controlnet in CONTROLNET_DICT_SD.keys() or controlnet in CONTROLNET_DICT_SD_XL.keys() or controlnet is None
     assert sampler in ["ddim", "unipcmultistep"]
+    if base_model == "blip_diffusion" and controlnet == "canny" and not SDEdit:
+        # run_aug/run_aug.py:178-181, :211: BlipDiffusionControlNetPipeline from Salesforce/blipdiffusion-controlnet; the
+        # checkpoint's PNDM scheduler is KEPT (:217 switches only non-BLIP pipelines to DDIM / UniPC)
+        cfgs = cfgs or BLIP_DIFFUSION
+        if state_dicts is not None:
+            return BlipDiffusionControlNetPipeline(state_dicts, cfgs)
+        if weights_dir:
+            return BlipDiffusionControlNetPipeline.from_pretrained(os.path.join(weights_dir, BASE_MODEL_DICT["blip_diffusion-controlnet"]), cfgs)
+        logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
+        return BlipDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0)
     if base_model != "sd_v1.5" or controlnet != "canny" or SDEdit:
         raise NotImplementedError(
-            f"({base_model}, {controlnet}, SDEdit={SDEdit}): only sd_v1.5 + canny ControlNet is built so far; "
-            "BLIP-Diffusion / SDXL-Turbo are SURVEY 8(a) rows a8 / a9, SDEdit / HED / ip2p are baseline branches")
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 and blip_diffusion with the canny ControlNet are built; "
+            "SDXL-Turbo is SURVEY 8(a) row a9, SDEdit / HED / ip2p / blip_diffusion-edit are baseline branches")
     if sampler != "ddim":
         raise NotImplementedError("UniPC sampler (SURVEY 8(f) f4)")
     cfgs = cfgs or SD15
@@ -172,11 +184,24 @@ def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strengt
     """Single-variant call form of the reference (name kept, typo included)."""
     pipe_args = {"prompt": str(prompt), "num_inference_steps": num_inference_steps, "generator": generator,
                  "guidance_scale": guidance_scale, "negative_prompt": negative_prompt}
-    if "blip_diffusion" in base_model or "ip2p" in base_model or SDEdit:
-        raise NotImplementedError("only the sd_v1.5 + ControlNet call form is built")
+    if "ip2p" in base_model or SDEdit or base_model == "blip_diffusion-edit":
+        raise NotImplementedError("only the sd_v1.5 / blip_diffusion + ControlNet call forms are built")
+    if "blip_diffusion" in base_model:                     # run_aug/run_aug.py:243-250
+        pipe_args["reference_image"] = orig_img
+        pipe_args["source_subject_category"] = blip_src_category
+        pipe_args["target_subject_category"] = blip_target_category
+        pipe_args["height"] = orig_img.size[1]
+        pipe_args["width"] = orig_img.size[0]
+        pipe_args["neg_prompt"] = NEGATIVE_PROMPT
+        del pipe_args["negative_prompt"]
     if control_image is not None:
-        pipe_args["image"] = control_image
-        pipe_args["controlnet_conditioning_scale"] = control_cond_scale
+        if "blip_diffusion" in base_model:                 # :262-265 -- note: no conditioning scale is passed
+            pipe_args["condtioning_image"] = control_image
+            pipe_args["height"] = control_image.size[1]
+            pipe_args["width"] = control_image.size[0]
+        else:
+            pipe_args["image"] = control_image
+            pipe_args["controlnet_conditioning_scale"] = control_cond_scale
     output = pipe(**pipe_args)
     return output.images[0]
 
@@ -202,7 +227,8 @@ def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image
     return prompt
 
 
-def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None):
+def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None,
+              same_class_fn=None):
     """Returns the work items in the reference's loop order.  Must be called right after
     utils.set_seed(SEED) (and dataset construction), like the reference's loop."""
     if image_size_fn is None:
@@ -228,8 +254,10 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
             output_path = Path(output_folder) / f"{image_stem[:MAX_FILENAME_LENGTH]}_prompt_{prompt.replace('/', '-')}_{i}.png"
             it = WorkItem(len(items), index, source_image_path, image_stem, i, prompt, str(output_path), th, tw)
             if output_path.exists():
-                it.skip = True               # :430-432 -- skipped BEFORE the noise draw
+                it.skip = True               # :430-432 -- skipped BEFORE the subject / noise draws
             else:
+                if "blip_diffusion" in s.BASE_MODEL and s.STYLE_IMG_FROM_DIFF_IMG:
+                    it.subject_path = random.choice(same_class_fn(source_image_path))     # :446 (python RNG stream)
                 it.noise_offset = noise_cursor
                 noise_cursor += 4 * (th // 8) * (tw // 8)
             items.append(it)
@@ -289,13 +317,23 @@ def hip_batch_generator(pipe, s: Settings):
     tok = pipe.tokenizer
     neg_ids = tok(NEGATIVE_PROMPT)
 
-    def run(batch, noises, sources):
+    blip = "blip_diffusion" in s.BASE_MODEL
+
+    def run(batch, noises, sources, subjects=None, category=None):
         src = torch.from_numpy(np.ascontiguousarray(sources)).to(pipe.device)
-        ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)
-        ids = np.concatenate([tok(it.prompt) for it in batch])
+        ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
         lat = torch.cat(noises)
-        out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
-                                  s.CONTROLNET_CONDITIONING_SCALE)
+        if blip:
+            # subject tokens from the same-class image (or the image itself), amplified "a {category} {prompt}" prompt
+            # tokenised to 77 - 16 tokens, no conditioning scale (run_aug/run_aug.py:243-250, 262-265, 444-456)
+            refs = subjects if subjects is not None else list(sources)
+            q = pipe.get_query_embeddings(refs, [category] * len(batch))
+            ids = np.concatenate([tok(pipe.build_prompt(it.prompt, category), max_len=pipe.prompt_token_count()) for it in batch])
+            out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE, 1.0, query_embeds=q)
+        else:
+            ids = np.concatenate([tok(it.prompt) for it in batch])
+            out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
+                                      s.CONTROLNET_CONDITIONING_SCALE)
         return out.cpu().numpy(), ctrl.cpu().numpy()
     return run
 
@@ -330,7 +368,9 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
                                             model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING)
     logging.info(f"Augmented json path will be at: \n{aug_json_path}")
 
-    items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict)
+    blip = "blip_diffusion" in s.BASE_MODEL
+    items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict,
+                      same_class_fn=ds_utils.get_image_path_with_same_class if blip else None)
     mine = shard_items(items, world)[rank]
     logging.info(f"rank {rank}/{world}: {len(mine)} of {len(items)} work items ({sum(i.skip for i in items)} already exist)")
 
@@ -353,7 +393,12 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     for batch in make_batches(mine, s.BATCH_SIZE):
         try:
             sources = np.stack([load_source(it.source_path, s.RESOLUTION) for it in batch])
-            images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources)
+            if blip:
+                subjects = [load_source(it.subject_path, s.RESOLUTION) if it.subject_path else sources[k] for k, it in enumerate(batch)]
+                images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources, subjects, ds_utils.meta_class)
+            else:
+                subjects = None
+                images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources)
         except KeyboardInterrupt:
             raise
         except RuntimeError as e:            # the reference treats RuntimeError as OOM (:493-500); isolate per batch
@@ -371,6 +416,8 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
                 futures.append(pool.submit(Image.fromarray(sources[k]).save, os.path.join(output_folder, f"{stem40}_source.png")))
                 if it.index < 10:
                     futures.append(pool.submit(Image.fromarray(controls[k]).save, f"{output_folder}/{stem40}_control.png"))
+            if subjects is not None and it.subject_path:     # :453-454 "_subject_{i}.png" (excluded from the JSON by name)
+                futures.append(pool.submit(Image.fromarray(subjects[k]).save, os.path.join(output_folder, f"{stem40}_subject_{it.i}.png")))
             futures.append(pool.submit(Image.fromarray(images[k]).save, it.output_path))
             it.status = 1
     for f in futures:

@@ -214,4 +214,6 @@ def test_pipeline_refuses_cpu():
     with pytest.raises(RuntimeError):
         pipe(prompt="x", image=Image.new("RGB", (64, 64)))
     with pytest.raises(NotImplementedError):
-        R.init_pipeline("blip_diffusion", "canny", 0)
+        R.init_pipeline("sd_xl-turbo", "canny", 0)          # not built yet
+    with pytest.raises(NotImplementedError):
+        R.init_pipeline("blip_diffusion", "canny", 1)       # SDEdit is a baseline branch

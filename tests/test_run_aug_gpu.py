@@ -1,0 +1,50 @@
+"""End-to-end run of the generation loop (saspa_aug_amd.run_aug.main) on the device with reduced-width synthetic
+weights and an on-disk synthetic dataset: both built model families, output tree, side files and the JSON contract."""
+import json
+from pathlib import Path
+
+import pytest
+import torch
+
+import saspa_aug_amd  # noqa: F401
+from saspa_aug_amd import config as CFG
+from saspa_aug_amd import run_aug as R
+from saspa_aug_amd import weights as W
+from saspa_aug_amd.pipeline import BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(tmp_path, base_model, **kw):
+    prompts = tmp_path / "prompts.txt"
+    prompts.write_text("".join(f"an airplane in scene {k}.\n" for k in range(6)))
+    return R.Settings(DATASET="synthetic", BASE_MODEL=base_model, RESOLUTION=64, NUM_INFERENCE_STEPS=3, NUM_PER_IMAGE=2, SEED=1,
+                      USE_ARTISTIC_PROMPTS=(base_model == "sd_v1.5"), SEMANTIC_FILTERING=0, MODEL_CONFIDENCE_BASED_FILTERING=0,
+                      PROMPTS_FILE=str(prompts), BATCH_SIZE=4,
+                      DATASET_KWARGS=dict(root_path=str(tmp_path / "ds" / "data"), n_images=5, sizes=((64, 64), (64, 128))), **kw)
+
+
+@pytest.mark.parametrize("base_model", ["sd_v1.5", "blip_diffusion"])
+def test_run_aug_end_to_end(dev, tmp_path, base_model):
+    cfgs = CFG.tiny()
+    fam = W.synth_family(cfgs, seed=3)
+    cls = BlipDiffusionControlNetPipeline if base_model == "blip_diffusion" else StableDiffusionControlNetPipeline
+    pipe = cls(fam, cfgs).to("cuda:0", torch.float16)
+    s = _settings(tmp_path, base_model)
+    res = R.main(s, pipe=pipe)
+    out = Path(res["output_folder"])
+    assert f"aug_data/controlnet/{base_model}/canny/" in str(out)
+    assert (res["status"] == 1).all() and len(res["items"]) == 10
+    pngs = sorted(p.name for p in out.glob("*.png"))
+    gen = [n for n in pngs if "_prompt_" in n]
+    assert len(gen) == 10 and len([n for n in pngs if n.endswith("_source.png")]) == 5
+    assert len([n for n in pngs if n.endswith("_control.png")]) == 5
+    if base_model == "blip_diffusion":
+        assert len([n for n in pngs if "_subject_" in n]) == 10
+        assert all(it.subject_path for it in res["items"])
+    body = json.load(open(res["json_path"]))
+    assert len(body) == 5 and all(len(v) == 2 for v in body.values())
+    assert all("_subject_" not in p and "_source" not in p and "_control" not in p for v in body.values() for p in v)
+    # a second run finds every output on disk and generates nothing
+    res2 = R.main(s, pipe=pipe)
+    assert all(it.skip for it in res2["items"]) and (res2["status"] == 0).all()

@@ -181,6 +181,11 @@ int saspa_cfg_plms_step(int dtype, const void* eps, void* x, void* hist, const v
 int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc,
                         float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
                         float sqrt_1m_a_prev, void* stream);
+/* DDIM step (eta=0) without classifier-free guidance: eps, x [nimg][hw][ldc], x updated in place.  The
+ * SDXL-Turbo operating point of the reference (guidance_scale 0 -> one conditional evaluation per step,
+ * run_aug/run_aug.py:564-571; SURVEY 8a: a9). */
+int saspa_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, float sqrt_a_t,
+                    float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, void* stream);
 /* y = x * s  (latents / scaling_factor before the VAE) */
 int saspa_scale(int dtype, const void* x, void* y, long long n, float s, void* stream);
 /* u8 RGB [n][H*W][3] -> [n][H*W][8] activations in [0,1], pad channels zero

@@ -17,18 +17,22 @@ class DDIM:
     0.00085..0.012 over 1000 steps, steps_offset=1, set_alpha_to_one=False,
     clip_sample=False, epsilon prediction, "leading" spacing."""
 
-    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, spacing="leading"):
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = self.alphas_cumprod[0]
         self.num_train = num_train
         self.steps_offset = steps_offset
+        self.spacing = spacing
         self.init_noise_sigma = 1.0
 
     def set_timesteps(self, n):
         self.n = n
-        ratio = self.num_train // n
-        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        if self.spacing == "trailing":      # SDXL-Turbo's scheduler config (timestep_spacing="trailing")
+            ts = np.round(np.arange(self.num_train, 0, -self.num_train / n)).astype(np.int64) - 1
+        else:
+            ratio = self.num_train // n
+            ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
         self.timesteps = ts
         return ts
 
@@ -164,6 +168,36 @@ def blip_controlnet_pipeline(weights, cfgs, ids_prompt, ids_neg, query_embeds, c
         eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
         eps_u, eps_c = eps2.chunk(2)
         eps = eps_u + guidance_scale * (eps_c - eps_u)
+        x = sch.step(eps, t, x)
+    img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
+    out = postprocess(img)
+    if return_latents:
+        return out, x, img
+    return out
+
+
+@torch.no_grad()
+def sdxl_controlnet_pipeline(weights, cfgs, ids1, ids2, control_u8, latents, steps, conditioning_scale=0.75,
+                             return_latents=False):
+    """StableDiffusionXLControlNetPipeline.__call__ as the reference invokes it for sd_xl-turbo
+    (run_aug/run_aug.py:189-201, :223-228, :564-571): guidance_scale 0 -> NO classifier-free guidance (one
+    conditional evaluation per step, no negative prompt), 2 steps, DDIMScheduler.from_config(<SDXL-Turbo scheduler
+    config>) -> "trailing" timesteps, set_alpha_to_one=False, clip_sample=False; conditioning scale 0.75 (:269);
+    VAE = sdxl-vae-fp16-fix upcast to fp32, scaling factor 0.13025.
+    ids1 / ids2: int64 [1,77] from tokenizer (EOS-padded) / tokenizer_2 (0-padded).  Prompt embedding = concat of the
+    two towers' hidden_states[-2]; pooled = text_encoder_2's projected EOS state; add_time_ids = (H, W, 0, 0, H, W)."""
+    h1, _ = M.clip_text_forward(weights["text"], cfgs["text"], ids1, penultimate=True)
+    h2, pooled = M.clip_text_forward(weights["text2"], cfgs["text2"], ids2, penultimate=True)
+    ctx = torch.cat([h1, h2], dim=-1)
+    hh, ww = control_u8.shape[:2]
+    added = dict(text_embeds=pooled, time_ids=torch.tensor([[hh, ww, 0, 0, hh, ww]], dtype=torch.float32))
+    cond = prepare_control(control_u8)
+    sch = DDIM(spacing="trailing")
+    x = latents.clone().float() * sch.init_noise_sigma
+    for t in sch.set_timesteps(steps):
+        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x, int(t), ctx, cond,
+                                         conditioning_scale, added)
+        eps = M.unet_forward(weights["unet"], cfgs["unet"], x, int(t), ctx, down, mid, added)
         x = sch.step(eps, t, x)
     img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
     out = postprocess(img)

@@ -128,16 +128,59 @@ def basic_transformer_block(sd, pfx, h, ctx, heads):
     return h
 
 
-def transformer_2d(sd, pfx, x, ctx, heads, groups):
+def transformer_2d(sd, pfx, x, ctx, heads, groups, depth=1, linear_proj=False):
+    """Transformer2DModel: conv projections around ONE block (SD-1.5, use_linear_projection=False) or linear
+    projections applied to the token matrix around ``depth`` blocks (SDXL, use_linear_projection=True)."""
     b, c, hh, ww = x.shape
     res = x
     h = group_norm(sd, pfx + ".norm", x, groups, 1e-6)
-    h = conv2d(sd, pfx + ".proj_in", h, padding=0)      # use_linear_projection=False
-    h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-    h = basic_transformer_block(sd, pfx + ".transformer_blocks.0", h, ctx, heads)
-    h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
-    h = conv2d(sd, pfx + ".proj_out", h, padding=0)
+    if linear_proj:
+        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+        h = linear(sd, pfx + ".proj_in", h)
+    else:
+        h = conv2d(sd, pfx + ".proj_in", h, padding=0)
+        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+    for d in range(depth):
+        h = basic_transformer_block(sd, f"{pfx}.transformer_blocks.{d}", h, ctx, heads)
+    if linear_proj:
+        h = linear(sd, pfx + ".proj_out", h)
+        h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+    else:
+        h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+        h = conv2d(sd, pfx + ".proj_out", h, padding=0)
     return h + res
+
+
+def _lvl(cfg, i):
+    """(heads, depth) of level i: SD-1.5 has one head count and depth 1; SDXL has per-level tuples."""
+    heads = cfg["heads"][i] if isinstance(cfg["heads"], (tuple, list)) else cfg["heads"]
+    depth = cfg["depth"][i] if "depth" in cfg else 1
+    return heads, depth
+
+
+def _tr(sd, cfg, pfx, x, ctx, lvl):
+    heads, depth = _lvl(cfg, lvl)
+    return transformer_2d(sd, pfx, x, ctx, heads, cfg["groups"], depth, cfg.get("linear_proj", False))
+
+
+def added_embedding(sd, cfg, text_embeds, time_ids):
+    """SDXL addition_embed_type "text_time" (UNet2DConditionModel.get_aug_embed): each of the 6 size / crop ids
+    through Timesteps(256, flip_sin_to_cos=True, freq_shift=0), flattened, appended AFTER the pooled text
+    embedding, then TimestepEmbedding(2816 -> 1280).  text_embeds [B, pooled], time_ids [B, 6]."""
+    ae = cfg["add_embed"]
+    b = text_embeds.shape[0]
+    te = timestep_sinusoid(time_ids.reshape(-1), ae["time_dim"]).reshape(b, -1)
+    e = torch.cat([text_embeds, te], dim=-1)
+    e = F.silu(linear(sd, "add_embedding.linear_1", e))
+    return linear(sd, "add_embedding.linear_2", e)
+
+
+def _emb(sd, cfg, t, batch, added):
+    t = torch.as_tensor(t).reshape(-1).expand(batch)
+    emb = time_embedding(sd, "time_embedding", t, cfg["block_out"][0])
+    if "add_embed" in cfg:
+        emb = emb + added_embedding(sd, cfg, added["text_embeds"], added["time_ids"])
+    return emb
 
 
 # --------------------------------------------------------------------------
@@ -150,13 +193,13 @@ def _encoder(sd, cfg, sample, emb, ctx):
         for j in range(cfg["layers"]):
             sample = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", sample, emb, cfg["groups"], 1e-5)
             if cfg["attn"][i]:
-                sample = transformer_2d(sd, f"down_blocks.{i}.attentions.{j}", sample, ctx, cfg["heads"], cfg["groups"])
+                sample = _tr(sd, cfg, f"down_blocks.{i}.attentions.{j}", sample, ctx, i)
             res += (sample,)
         if i != n_lvl - 1:
             sample = conv2d(sd, f"down_blocks.{i}.downsamplers.0.conv", sample, stride=2, padding=1)
             res += (sample,)
     sample = resnet_block(sd, "mid_block.resnets.0", sample, emb, cfg["groups"], 1e-5)
-    sample = transformer_2d(sd, "mid_block.attentions.0", sample, ctx, cfg["heads"], cfg["groups"])
+    sample = _tr(sd, cfg, "mid_block.attentions.0", sample, ctx, n_lvl - 1)
     sample = resnet_block(sd, "mid_block.resnets.1", sample, emb, cfg["groups"], 1e-5)
     return sample, res
 
@@ -171,11 +214,11 @@ def controlnet_cond_embedding(sd, cfg, cond):
     return conv2d(sd, pfx + ".conv_out", e)
 
 
-def controlnet_forward(sd, cfg, sample, t, ctx, cond, conditioning_scale=1.0):
+def controlnet_forward(sd, cfg, sample, t, ctx, cond, conditioning_scale=1.0, added=None):
     """ControlNetModel.forward: returns (12 down residuals, mid residual), each
-    already multiplied by ``conditioning_scale`` (run_aug/run_aug.py:269 passes 0.75)."""
-    t = torch.as_tensor(t).reshape(-1).expand(sample.shape[0])
-    emb = time_embedding(sd, "time_embedding", t, cfg["block_out"][0])
+    already multiplied by ``conditioning_scale`` (run_aug/run_aug.py:269 passes 0.75).
+    ``added`` = dict(text_embeds, time_ids) for the SDXL text_time conditioning."""
+    emb = _emb(sd, cfg, t, sample.shape[0], added)
     sample = conv2d(sd, "conv_in", sample)
     sample = sample + controlnet_cond_embedding(sd, cfg, cond)
     mid, res = _encoder(sd, cfg, sample, emb, ctx)
@@ -186,11 +229,10 @@ def controlnet_forward(sd, cfg, sample, t, ctx, cond, conditioning_scale=1.0):
     return out, mid
 
 
-def unet_forward(sd, cfg, sample, t, ctx, down_residuals=None, mid_residual=None):
+def unet_forward(sd, cfg, sample, t, ctx, down_residuals=None, mid_residual=None, added=None):
     """UNet2DConditionModel.forward with ControlNet residuals added to the 12
     skips and to the mid-block output."""
-    t = torch.as_tensor(t).reshape(-1).expand(sample.shape[0])
-    emb = time_embedding(sd, "time_embedding", t, cfg["block_out"][0])
+    emb = _emb(sd, cfg, t, sample.shape[0], added)
     sample = conv2d(sd, "conv_in", sample)
     sample, res = _encoder(sd, cfg, sample, emb, ctx)
     if down_residuals is not None:
@@ -206,7 +248,7 @@ def unet_forward(sd, cfg, sample, t, ctx, down_residuals=None, mid_residual=None
             sample = torch.cat([sample, skip], dim=1)
             sample = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", sample, emb, cfg["groups"], 1e-5)
             if rev_attn[i]:
-                sample = transformer_2d(sd, f"up_blocks.{i}.attentions.{j}", sample, ctx, cfg["heads"], cfg["groups"])
+                sample = _tr(sd, cfg, f"up_blocks.{i}.attentions.{j}", sample, ctx, n_lvl - 1 - i)
         if i != n_lvl - 1:
             sample = F.interpolate(sample, scale_factor=2.0, mode="nearest")
             sample = conv2d(sd, f"up_blocks.{i}.upsamplers.0.conv", sample)
@@ -255,7 +297,7 @@ def vae_decode(sd, cfg, z):
 # --------------------------------------------------------------------------
 # CLIP text tower (last_hidden_state after final LN; causal mask; quick-GELU)
 # --------------------------------------------------------------------------
-def clip_text_forward(sd, cfg, ids, ctx_embeddings=None, ctx_begin_pos=2):
+def clip_text_forward(sd, cfg, ids, ctx_embeddings=None, ctx_begin_pos=2, penultimate=False):
     """CLIPTextModel; with ``ctx_embeddings`` [B, nctx, width] it is BLIP-Diffusion's ContextCLIPTextModel
     ([upstream] diffusers blip_diffusion/modeling_ctx_clip.py, recalled): the subject tokens are spliced into the
     token embeddings at ``ctx_begin_pos`` BEFORE the position embeddings (of the lengthened sequence) are added."""
@@ -266,6 +308,7 @@ def clip_text_forward(sd, cfg, ids, ctx_embeddings=None, ctx_begin_pos=2):
     b, n = tok.shape[:2]
     x = tok + sd[pfx + ".embeddings.position_embedding.weight"][:n][None]
     mask = torch.full((n, n), float("-inf")).triu_(1)
+    hidden = [x]
     for i in range(cfg["layers"]):
         lp = f"{pfx}.encoder.layers.{i}"
         h = layer_norm(sd, lp + ".layer_norm1", x)
@@ -276,6 +319,17 @@ def clip_text_forward(sd, cfg, ids, ctx_embeddings=None, ctx_begin_pos=2):
         x = x + linear(sd, lp + ".self_attn.out_proj", o)
         h = layer_norm(sd, lp + ".layer_norm2", x)
         h = linear(sd, lp + ".mlp.fc1", h)
-        h = h * torch.sigmoid(1.702 * h)
+        h = F.gelu(h) if cfg.get("act") == "gelu" else h * torch.sigmoid(1.702 * h)
         x = x + linear(sd, lp + ".mlp.fc2", h)
-    return layer_norm(sd, pfx + ".final_layer_norm", x)
+        hidden.append(x)
+    last = layer_norm(sd, pfx + ".final_layer_norm", x)
+    if not penultimate:
+        return last
+    # SDXL encode_prompt: hidden_states[-2] of the tower (no final LayerNorm); for CLIPTextModelWithProjection
+    # also text_embeds = text_projection(last_hidden_state[eos]), eos = first position holding the largest id
+    # (eos_token_id == 2 legacy branch of transformers' CLIPTextTransformer: input_ids.argmax(-1)).
+    pooled = None
+    if "text_projection.weight" in sd:
+        eos = ids.argmax(dim=-1)
+        pooled = F.linear(last[torch.arange(b), eos], sd["text_projection.weight"])
+    return hidden[-2], pooled

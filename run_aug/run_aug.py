@@ -6,7 +6,7 @@ the reference's run_aug/run_aug.py:513-556) and run
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_aug/run_aug.py   # 8 MI355X
 
 Environment overlays (optional): SASPA_DATASET, SASPA_WEIGHTS_DIR, SASPA_PROMPTS_FILE,
-SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION, SASPA_BASE_MODEL (sd_v1.5 | blip_diffusion)."""
+SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION, SASPA_BASE_MODEL (sd_v1.5 | blip_diffusion | sd_xl-turbo)."""
 import os
 import sys
 from pathlib import Path
@@ -48,6 +48,13 @@ if __name__ == "__main__":
 
     if "cars" in DATASET.lower():
         NUM_INFERENCE_STEPS = 50
+    if DATASET.lower() == "cub":                      # reference :564-565
+        BASE_MODEL = "sd_xl-turbo"
+    if BASE_MODEL == "sd_xl-turbo":                   # reference :567-571
+        print("Using sd_xl-turbo, setting some params accordingly")
+        GUIDANCE_SCALE = 0
+        NUM_INFERENCE_STEPS = 2
+        R.NEGATIVE_PROMPT = None
 
     s = R.Settings(DEBUG=DEBUG, SPECIFIC_FILE_STRs=SPECIFIC_FILE_STRs, DEVICE=DEVICE, version=version, DATASET=DATASET,
                    BASE_MODEL=BASE_MODEL, CONTROLNET=CONTROLNET, SDEDIT=SDEDIT, NUM_PER_IMAGE=NUM_PER_IMAGE, SEED=SEED,

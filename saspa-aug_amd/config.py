@@ -18,6 +18,26 @@ CLIP_L = dict(vocab=49408, width=768, layers=12, heads=12, mlp=3072, max_pos=77)
 
 SD15 = dict(unet=SD15_UNET, controlnet=SD15_CONTROLNET, vae=SD15_VAE, text=CLIP_L)
 
+# stabilityai/sdxl-turbo (= SDXL-base architecture) : unet/config.json.  Three levels, no attention at level 0,
+# transformer_layers_per_block (1, 2, 10) -> "depth" (level 0 unused), attention_head_dim (5, 10, 20) = heads per
+# level (head dim 64 everywhere), cross_attention_dim 2048 (CLIP-L 768 | OpenCLIP-bigG 1280), use_linear_projection,
+# addition_embed_type "text_time": 6 size/crop ids x Timesteps(256) | pooled bigG text embedding (1280) -> 2816 -> 1280.
+# Values recalled from the public repos (no network here): parity unpinned.
+SDXL_UNET = dict(
+    in_channels=4, out_channels=4, block_out=(320, 640, 1280), attn=(False, True, True), depth=(0, 2, 10),
+    layers=2, heads=(5, 10, 20), ctx_dim=2048, groups=32, temb_dim=1280, linear_proj=True,
+    add_embed=dict(time_dim=256, n_ids=6, pooled_dim=1280),
+)
+# diffusers/controlnet-canny-sdxl-1.0 : config.json (run_aug/run_aug.py:70)
+SDXL_CONTROLNET = dict(SDXL_UNET, cond_channels=3, cond_embed=(16, 32, 96, 256))
+# madebyollin/sdxl-vae-fp16-fix (run_aug/run_aug.py:189): the SD VAE architecture, scaling_factor 0.13025
+SDXL_VAE = dict(SD15_VAE, scaling_factor=0.13025)
+# text_encoder: CLIP-L as above; text_encoder_2: CLIPTextModelWithProjection (OpenCLIP ViT-bigG/14 text tower):
+# 32 layers, width 1280, 20 heads, MLP 5120, erf-GELU, pad token id 0, text_projection 1280 -> 1280 (no bias).
+# The SDXL pipelines read hidden_states[-2] of BOTH towers (output of the second-to-last layer, no final LayerNorm).
+OPENCLIP_BIGG = dict(vocab=49408, width=1280, layers=32, heads=20, mlp=5120, max_pos=77, act="gelu", proj_dim=1280, pad_id=0)
+SDXL_TURBO = dict(unet=SDXL_UNET, controlnet=SDXL_CONTROLNET, vae=SDXL_VAE, text=CLIP_L, text2=OPENCLIP_BIGG)
+
 # Salesforce/blipdiffusion(-controlnet) : qformer/config.json (Blip2QFormerModel = CLIP-L/14 vision tower with its
 # last block dropped + BERT-base Q-Former with 16 learned queries + ProjLayer), image processor mean/std, ctx_begin_pos.
 # Values recalled from the public repo / LAVIS BlipDiffusion defaults (no network here): parity unpinned.
@@ -29,6 +49,20 @@ BLIP2_QFORMER = dict(
 BLIP_IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
 BLIP_IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
 BLIP_DIFFUSION = dict(SD15, qformer=BLIP2_QFORMER, ctx_begin_pos=2)
+
+
+def tiny_xl(width=32, ctx1=32, ctx2=64, groups=8, vae_width=16):
+    """Reduced-width SDXL family with the same topology: 3 levels, no attention at level 0, transformer depths
+    (2, 3), linear projections, head dim 16, two text towers (ctx1 | ctx2), text_time addition embedding."""
+    unet = dict(in_channels=4, out_channels=4, block_out=(width, 2 * width, 4 * width), attn=(False, True, True),
+                depth=(0, 2, 3), layers=2, heads=(2, 4, 8), ctx_dim=ctx1 + ctx2, groups=groups, temb_dim=4 * width,
+                linear_proj=True, add_embed=dict(time_dim=16, n_ids=6, pooled_dim=ctx2))
+    cn = dict(unet, cond_channels=3, cond_embed=(8, 16, 24, 32))
+    vae = dict(latent_channels=4, out_channels=3, block_out=(vae_width, 2 * vae_width, 4 * vae_width, 4 * vae_width),
+               layers=2, groups=groups, scaling_factor=0.13025)
+    text = dict(vocab=512, width=ctx1, layers=3, heads=2, mlp=4 * ctx1, max_pos=77)
+    text2 = dict(vocab=512, width=ctx2, layers=3, heads=4, mlp=4 * ctx2, max_pos=77, act="gelu", proj_dim=ctx2, pad_id=0)
+    return dict(unet=unet, controlnet=cn, vae=vae, text=text, text2=text2)
 
 
 def tiny(width=32, ctx=64, groups=8, heads=4, vae_width=16):

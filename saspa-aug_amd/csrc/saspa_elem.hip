@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hi
 }
 
 // CFG + DDIM (eta = 0).  One item = one pixel (ldc == 8 channels, C live).
-template <typename T>
+// CFG == false: plain DDIM step on nimg samples (guidance off: SDXL-Turbo, run_aug/run_aug.py:568).
+template <typename T, bool CFG>
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* eps, T* x, int nimg, long long hw, int C, float g, float sa_t,
                                                        float s1m_t, float sa_p, float s1m_p) {
   const long long total = (long long)nimg * hw;
@@ -151,16 +152,16 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* eps, T* x, int n
   for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
     float eu[8], ec[8], xv[8], o[8];
     load8(eps + it * 8, eu);
-    load8(eps + half + it * 8, ec);
+    if (CFG) load8(eps + half + it * 8, ec);
     load8(x + it * 8, xv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = eu[j] + g * (ec[j] - eu[j]);
+      const float e = CFG ? eu[j] + g * (ec[j] - eu[j]) : eu[j];
       const float x0 = (xv[j] - s1m_t * e) / sa_t;
       o[j] = (j < C) ? (sa_p * x0 + s1m_p * e) : 0.f;
     }
     store8(x + it * 8, o);
-    store8(x + half + it * 8, o);
+    if (CFG) store8(x + half + it * 8, o);
   }
 }
 
@@ -292,9 +293,27 @@ extern "C" int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned grid = grid_for((long long)nimg * hw);
   if (dtype == SASPA_BF16)
-    hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+    hipLaunchKernelGGL((cfg_ddim_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
   else if (dtype == SASPA_F32)
-    hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+    hipLaunchKernelGGL((cfg_ddim_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, float sqrt_a_t,
+                               float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, void* stream) {
+  if (!eps || !x || nimg <= 0 || hw <= 0 || C <= 0) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x)) return SASPA_EALIGN;
+  if (!(sqrt_a_t > 0.f)) return SASPA_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL((cfg_ddim_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, 0.f, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL((cfg_ddim_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, 0.f, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev);
   else
     return SASPA_EINVAL;
   SASPA_CHECK_LAUNCH();
@@ -343,5 +362,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 2; }
+extern "C" int saspa_abi_version(void) { return 3; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

@@ -40,6 +40,8 @@ class _Packed:
 
     def conv(self, name, split=None):
         w = self.sd[name + ".weight"]
+        if w.dim() == 2:            # use_linear_projection (SDXL): a Linear over the token matrix == a 1x1 conv
+            w = w[:, :, None, None]
         if split is None:
             pk = W.pack_conv(w)
         else:
@@ -138,72 +140,107 @@ class _Net:
             pk.linear(pfx + ".time_emb_proj", torch.float32)
             self.resnets_with_temb.append(pfx)
 
-    def _pack_transformer(self, pfx):
+    def _lvl(self, i):
+        """(heads, depth) of level i: SD-1.5 = (8, 1) everywhere, SDXL per-level tuples (config.SDXL_UNET)."""
+        cfg = self.cfg
+        heads = cfg["heads"][i] if isinstance(cfg["heads"], (tuple, list)) else cfg["heads"]
+        return heads, (cfg["depth"][i] if "depth" in cfg else 1)
+
+    def _pack_transformer(self, pfx, lvl):
         pk = self.pk
+        heads, depth = self._lvl(lvl)
         pk.norm(pfx + ".norm")
         pk.conv(pfx + ".proj_in")
-        t = pfx + ".transformer_blocks.0"
-        for n in ("norm1", "norm2", "norm3"):
-            pk.norm(f"{t}.{n}")
-        pk.attn(t + ".attn1", True)
-        pk.attn(t + ".attn2", False)
-        packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
-            if self.dtype == torch.bfloat16 else None
-        if packed is not None:          # bf16: GEGLU fused into the projection's epilogue
-            self.p[t + ".ff.net.0.proj.w"] = packed[0].to(self.dev, self.dtype)
-            self.p[t + ".ff.net.0.proj.b"] = _f32(packed[1], self.dev)
-            self.fused_geglu.add(t)
-        else:
-            pk.linear(t + ".ff.net.0.proj")
-        pk.linear(t + ".ff.net.2")
+        for d in range(depth):
+            t = f"{pfx}.transformer_blocks.{d}"
+            for n in ("norm1", "norm2", "norm3"):
+                pk.norm(f"{t}.{n}")
+            pk.attn(t + ".attn1", True)
+            pk.attn(t + ".attn2", False)
+            packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
+                if self.dtype == torch.bfloat16 else None
+            if packed is not None:          # bf16: GEGLU fused into the projection's epilogue
+                self.p[t + ".ff.net.0.proj.w"] = packed[0].to(self.dev, self.dtype)
+                self.p[t + ".ff.net.0.proj.b"] = _f32(packed[1], self.dev)
+                self.fused_geglu.add(t)
+            else:
+                pk.linear(t + ".ff.net.0.proj")
+            pk.linear(t + ".ff.net.2")
+            self.blocks.append(t)
         pk.conv(pfx + ".proj_out")
-        self.transformers.append(pfx)
+        self.tr_info[pfx] = (heads, depth)
 
     def _pack_encoder(self):
         cfg, pk = self.cfg, self.pk
-        self.resnets_with_temb, self.transformers, self.fused_geglu = [], [], set()
+        self.resnets_with_temb, self.blocks, self.tr_info, self.fused_geglu = [], [], {}, set()
         pk.conv("conv_in")
         pk.linear("time_embedding.linear_1", torch.float32)
         pk.linear("time_embedding.linear_2", torch.float32)
+        if "add_embed" in cfg:
+            pk.linear("add_embedding.linear_1", torch.float32)
+            pk.linear("add_embedding.linear_2", torch.float32)
         n_lvl = len(cfg["block_out"])
         for i in range(n_lvl):
             for j in range(cfg["layers"]):
                 self._pack_resnet(f"down_blocks.{i}.resnets.{j}")
                 if cfg["attn"][i]:
-                    self._pack_transformer(f"down_blocks.{i}.attentions.{j}")
+                    self._pack_transformer(f"down_blocks.{i}.attentions.{j}", i)
             if i != n_lvl - 1:
                 pk.conv(f"down_blocks.{i}.downsamplers.0.conv")
         self._pack_resnet("mid_block.resnets.0")
-        self._pack_transformer("mid_block.attentions.0")
+        self._pack_transformer("mid_block.attentions.0", n_lvl - 1)
         self._pack_resnet("mid_block.resnets.1")
 
     # ---- hoisted, time-invariant state ----
-    def prepare_timesteps(self, timesteps):
-        """Time-embedding MLP and every resnet's time_emb_proj for ALL steps (fp32 GEMMs):
-        table[pfx] = [steps, Cout].  The sinusoid is host scheduler state, like the DDIM
-        coefficients (Timesteps(dim0, flip_sin_to_cos=True, freq_shift=0))."""
-        dim0 = self.cfg["block_out"][0]
-        half = dim0 // 2
-        t = torch.as_tensor(timesteps, dtype=torch.float32)
+    @staticmethod
+    def _sinusoid(values, dim):
+        """Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) of a 1-D list of values -> [n, dim] fp32 (host)."""
+        half = dim // 2
+        t = torch.as_tensor(values, dtype=torch.float32).reshape(-1)
         exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
         ang = t[:, None] * torch.exp(exponent)[None, :]
-        sinus = torch.cat([torch.cos(ang), torch.sin(ang)], -1).to(self.dev)
+        return torch.cat([torch.cos(ang), torch.sin(ang)], -1)
+
+    def prepare_timesteps(self, timesteps, added=None):
+        """Time-embedding MLP and every resnet's time_emb_proj for ALL steps (fp32 GEMMs):
+        table[pfx] = [steps, Cout].  The sinusoid is host scheduler state, like the DDIM
+        coefficients (Timesteps(dim0, flip_sin_to_cos=True, freq_shift=0)).
+        SDXL (`add_embed` in the config): `added` = (text_embeds [B, pooled] device fp32, time_ids [B, 6] host) adds
+        the per-sample text_time embedding, so the tables become [steps, B, Cout] (row vector per batch sample)."""
+        sinus = self._sinusoid(timesteps, self.cfg["block_out"][0]).to(self.dev)
         p = self.p
         e = ops.linear(sinus, p["time_embedding.linear_1.w"], p["time_embedding.linear_1.b"], act=SILU)
-        e = ops.linear(e, p["time_embedding.linear_2.w"], p["time_embedding.linear_2.b"])
+        e = ops.linear(e, p["time_embedding.linear_2.w"], p["time_embedding.linear_2.b"])       # [S, temb]
+        if "add_embed" in self.cfg:
+            if added is None:
+                raise ValueError("this network needs the SDXL added conditioning (text_embeds, time_ids)")
+            text_embeds, time_ids = added
+            ae = self.cfg["add_embed"]
+            b = text_embeds.shape[0]
+            te = self._sinusoid(torch.as_tensor(time_ids, dtype=torch.float32), ae["time_dim"]).reshape(b, -1).to(self.dev)
+            a_in = torch.cat([text_embeds.to(torch.float32), te], -1).contiguous()
+            a = ops.linear(a_in, p["add_embedding.linear_1.w"], p["add_embedding.linear_1.b"], act=SILU)
+            # emb[s][b] = time_emb[s] + aug[b]: the aug row block is the GEMM's residual, once per step
+            s_n = e.shape[0]
+            e_rep = e[:, None, :].expand(s_n, b, e.shape[1]).reshape(s_n * b, -1).contiguous()
+            a_rep = a[None].expand(s_n, b, a.shape[1]).reshape(s_n * b, -1).contiguous()
+            e = ops.linear(a_rep, p["add_embedding.linear_2.w"], p["add_embedding.linear_2.b"], residual=e_rep)
+            shape = (s_n, b, -1)
+        else:
+            shape = (e.shape[0], -1)
         se = ops.activation(e, SILU)
-        self.temb_tables = {pfx: ops.linear(se, p[pfx + ".time_emb_proj.w"], p[pfx + ".time_emb_proj.b"])
+        self.temb_tables = {pfx: ops.linear(se, p[pfx + ".time_emb_proj.w"], p[pfx + ".time_emb_proj.b"]).view(*shape)
                             for pfx in self.resnets_with_temb}
 
     def prepare_context(self, ctx):
         """Cross-attention K and V^T of every transformer block for a [B,77,ctx_dim] batch."""
         b, n, _ = ctx.shape
         self.ctx_kv = {}
-        for pfx in self.transformers:
-            a = pfx + ".transformer_blocks.0.attn2"
+        for t in self.blocks:
+            a = t + ".attn2"
             k = ops.linear(ctx, self.p[a + ".k.w"])                     # [B,77,C]
             vt = project_vt(ctx, self.p[a + ".v.w"], n)                 # [B,C,80]
-            self.ctx_kv[pfx] = (k, vt, n)
+            self.ctx_kv[t] = (k, vt, n)
 
     # ---- blocks ----
     def resnet(self, pfx, x, step, eps, x2=None):
@@ -220,31 +257,33 @@ class _Net:
         return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
 
     def transformer(self, pfx, x):
-        p, g, heads = self.p, self.cfg["groups"], self.cfg["heads"]
+        p, g = self.p, self.cfg["groups"]
+        heads, depth = self.tr_info[pfx]
         b, hh, ww, c = x.shape
         n = hh * ww
-        t = pfx + ".transformer_blocks.0"
         h = ops.groupnorm(x, p[pfx + ".norm.g"], p[pfx + ".norm.b"], g, 1e-6)
         h = ops.conv(h, p[pfx + ".proj_in.w"], p[pfx + ".proj_in.b"]).view(b, n, c)
-        # self-attention
-        n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
-        qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
-        vt = project_vt(n1, p[t + ".attn1.v.w"], n)
-        o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n)
-        h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
-        # cross-attention against the cached text K / V^T
-        n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
-        q = ops.linear(n2, p[t + ".attn2.q.w"])
-        k, vtc, nk = self.ctx_kv[pfx]
-        o = attention_core(q, k, vtc, heads, n, nk)
-        h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
-        # GEGLU feed-forward
-        n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
-        if t in self.fused_geglu:
-            ff = ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU)
-        else:
-            ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
-        h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
+        for d in range(depth):
+            t = f"{pfx}.transformer_blocks.{d}"
+            # self-attention
+            n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
+            qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
+            vt = project_vt(n1, p[t + ".attn1.v.w"], n)
+            o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n)
+            h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
+            # cross-attention against the cached text K / V^T
+            n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
+            q = ops.linear(n2, p[t + ".attn2.q.w"])
+            k, vtc, nk = self.ctx_kv[t]
+            o = attention_core(q, k, vtc, heads, n, nk)
+            h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
+            # GEGLU feed-forward
+            n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
+            if t in self.fused_geglu:
+                ff = ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU)
+            else:
+                ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
+            h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
         return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x)
 
     def encode(self, sample, step, conv_in_residual=None):
@@ -291,7 +330,7 @@ class UNet(_Net):
                 sk = skip_ch.pop()
                 self._pack_resnet(f"up_blocks.{i}.resnets.{j}", split=(prev, sk))
                 if list(reversed(cfg["attn"]))[i]:
-                    self._pack_transformer(f"up_blocks.{i}.attentions.{j}")
+                    self._pack_transformer(f"up_blocks.{i}.attentions.{j}", n_lvl - 1 - i)
                 prev = c
             if i != n_lvl - 1:
                 pk.conv(f"up_blocks.{i}.upsamplers.0.conv")
@@ -466,12 +505,21 @@ class CLIPText:
             pk.linear(lp + ".mlp.fc1")
             pk.linear(lp + ".mlp.fc2")
         pk.norm("text_model.final_layer_norm")
+        if "text_projection.weight" in sd:      # CLIPTextModelWithProjection (SDXL text_encoder_2)
+            p["text_projection.w"] = sd["text_projection.weight"].contiguous().to(dev, dtype)
         pk.sd = None
 
-    def forward(self, ids, ctx=None, ctx_begin=2):
+    def forward(self, ids, ctx=None, ctx_begin=2, penultimate=False):
         """ids: int [B,n] (device) -> [B,n,width]; with ctx [B,nctx,width] (BLIP-Diffusion subject tokens) the
-        sequence is the prompt with ctx spliced in at `ctx_begin` (ContextCLIPTextModel), n + nctx long."""
+        sequence is the prompt with ctx spliced in at `ctx_begin` (ContextCLIPTextModel), n + nctx long.
+        penultimate=True is the SDXL encode_prompt form: returns (hidden_states[-2], text_embeds) -- the output of
+        the second-to-last layer without the final LayerNorm, and (towers with a text_projection only) the projected
+        final-LayerNorm state at the EOS position (first position of the largest id), else None."""
         cfg, p = self.cfg, self.p
+        mlp_act = ops.ACT_GELU if cfg.get("act") == "gelu" else ops.ACT_QUICK_GELU
+        want_pooled = penultimate and "text_projection.w" in p
+        n_run = cfg["layers"] if (not penultimate or want_pooled) else cfg["layers"] - 1
+        hidden2 = None
         b, n = ids.shape
         c = cfg["width"]
         if ctx is None:
@@ -479,7 +527,9 @@ class CLIPText:
         else:
             x = ops.embed_tokens_ctx(ids, ctx.to(self.dtype), ctx_begin, p["tok"], p["pos"])
             n = x.shape[1]
-        for i in range(cfg["layers"]):
+        for i in range(n_run):
+            if i == cfg["layers"] - 1:
+                hidden2 = x
             lp = f"text_model.encoder.layers.{i}"
             a = lp + ".self_attn"
             h = ops.layernorm(x, p[lp + ".layer_norm1.g"], p[lp + ".layer_norm1.b"])
@@ -488,6 +538,13 @@ class CLIPText:
             o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, cfg["heads"], n, n, causal=True)
             x = ops.linear(o, p[a + ".o.w"], p[a + ".o.b"], residual=x)
             h = ops.layernorm(x, p[lp + ".layer_norm2.g"], p[lp + ".layer_norm2.b"])
-            h = ops.activation(ops.linear(h, p[lp + ".mlp.fc1.w"], p[lp + ".mlp.fc1.b"]), ops.ACT_QUICK_GELU)
+            h = ops.activation(ops.linear(h, p[lp + ".mlp.fc1.w"], p[lp + ".mlp.fc1.b"]), mlp_act)
             x = ops.linear(h, p[lp + ".mlp.fc2.w"], p[lp + ".mlp.fc2.b"], residual=x)
-        return ops.layernorm(x, p["text_model.final_layer_norm.g"], p["text_model.final_layer_norm.b"])
+        if not penultimate:
+            return ops.layernorm(x, p["text_model.final_layer_norm.g"], p["text_model.final_layer_norm.b"])
+        if not want_pooled:
+            return x, None
+        eos = ids.argmax(dim=-1)                                        # index bookkeeping only
+        rows = x[torch.arange(b, device=x.device), eos].contiguous()    # gather of the EOS rows (data movement)
+        rows = ops.layernorm(rows, p["text_model.final_layer_norm.g"], p["text_model.final_layer_norm.b"])
+        return hidden2, ops.linear(rows, p["text_projection.w"])

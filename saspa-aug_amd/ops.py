@@ -366,6 +366,15 @@ def cfg_ddim_step(eps, x, nimg, hw, c, guidance, sa_t, s1m_t, sa_p, s1m_p):
     return x
 
 
+def ddim_step(eps, x, nimg, hw, c, sa_t, s1m_t, sa_p, s1m_p):
+    """eps, x: [nimg, hw, 8]; DDIM update without CFG (SDXL-Turbo, guidance off), x in place."""
+    _check_dev(eps, x)
+    lib = _lib.load()
+    _lib.check(lib.saspa_ddim_step(_dt(x), _ptr(eps), _ptr(x), nimg, hw, c, 8, float(sa_t), float(s1m_t), float(sa_p),
+                                   float(s1m_p), _stream()), "saspa_ddim_step")
+    return x
+
+
 def scale(x, s, out=None):
     _check_dev(x, out)
     lib = _lib.load()

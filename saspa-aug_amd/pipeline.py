@@ -23,8 +23,8 @@ from PIL import Image
 
 from . import models, ops
 from . import weights as W
-from .config import BLIP_DIFFUSION, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD, SD15
-from .scheduler import DDIMScheduler, PNDMScheduler
+from .config import BLIP_DIFFUSION, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD, SD15, SDXL_TURBO
+from .scheduler import SDXL_TURBO_SCHEDULER_CONFIG, DDIMScheduler, PNDMScheduler
 from .tokenizer import make_bert_tokenizer, make_tokenizer
 
 
@@ -316,5 +316,155 @@ class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
         neg = self.tokenizer(neg_prompt or "")
         q = self.get_query_embeddings([reference_image], [source_subject_category])
         out = self.generate_batch(ids, neg, ctrl[None], lat, num_inference_steps, guidance_scale, 1.0, query_embeds=q)
+        arr = out.cpu().numpy()
+        return PipelineOutput([Image.fromarray(a) for a in arr], None)
+
+
+class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
+    """Drop-in for diffusers' `StableDiffusionXLControlNetPipeline` as the reference builds and calls it for
+    `BASE_MODEL = "sd_xl-turbo"` (its choice for CUB; run_aug/run_aug.py:189-201, :223-228, :564-571):
+
+        vae  = AutoencoderKL.from_pretrained("madebyollin/sdxl-vae-fp16-fix")
+        pipe = StableDiffusionXLControlNetPipeline.from_pretrained("stabilityai/sdxl-turbo", controlnet=<canny-sdxl>, vae=vae)
+        pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config); pipe.upcast_vae()
+        image = pipe(prompt=..., image=<canny PIL>, num_inference_steps=2, generator=..., guidance_scale=0,
+                     negative_prompt=None, controlnet_conditioning_scale=0.75).images[0]
+
+    Differences from the SD-1.5 pipeline, all mirrored: guidance_scale <= 1 -> NO classifier-free guidance (one
+    conditional evaluation per step, the negative prompt is never encoded); two text towers read at
+    hidden_states[-2] and concatenated to a 2048-wide context, the second tower's projected EOS state is the pooled
+    embedding of the `text_time` conditioning together with add_time_ids = (H, W, 0, 0, H, W); three-level UNet /
+    ControlNet with transformer depths (2, 10) and linear projections; VAE scaling factor 0.13025, decoded in fp32
+    after `upcast_vae()` (the exact-fp32 MFMA kernels) even when the denoiser runs in bf16."""
+
+    def __init__(self, state_dicts, cfgs=SDXL_TURBO, tokenizer=None, scheduler=None, tokenizer_2=None):
+        super().__init__(state_dicts, cfgs, tokenizer, scheduler or DDIMScheduler(**SDXL_TURBO_SCHEDULER_CONFIG))
+        self.tokenizer_2 = tokenizer_2 or make_tokenizer(vocab=cfgs["text2"]["vocab"])
+        self.text_encoder_2 = None
+        self._vae_fp32 = False
+        self._vae_sd = None
+
+    @classmethod
+    def from_synthetic(cls, cfgs=SDXL_TURBO, seed=0):
+        return cls(W.synth_family(cfgs, seed), cfgs)
+
+    @classmethod
+    def from_pretrained(cls, base_dir, controlnet_dir, vae_dir=None, cfgs=SDXL_TURBO):
+        """Local copies of stabilityai/sdxl-turbo (unet/ text_encoder/ text_encoder_2/ tokenizer/ tokenizer_2/ vae/),
+        diffusers/controlnet-canny-sdxl-1.0 and (optionally) madebyollin/sdxl-vae-fp16-fix."""
+        names = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "model.safetensors",
+                 "model.fp16.safetensors")
+
+        def f(d):
+            for n in names:
+                p = os.path.join(d, n)
+                if os.path.exists(p):
+                    return W.load_safetensors(p)
+            raise FileNotFoundError(f"no safetensors weights in {d}")
+        sds = dict(unet=f(os.path.join(base_dir, "unet")), vae=f(vae_dir or os.path.join(base_dir, "vae")),
+                   text=f(os.path.join(base_dir, "text_encoder")), text2=f(os.path.join(base_dir, "text_encoder_2")),
+                   controlnet=f(controlnet_dir))
+        return cls(sds, cfgs, tokenizer=make_tokenizer(os.path.join(base_dir, "tokenizer"), cfgs["text"]["vocab"]),
+                   tokenizer_2=make_tokenizer(os.path.join(base_dir, "tokenizer_2"), cfgs["text2"]["vocab"]))
+
+    def to(self, device, dtype=None):
+        self._vae_sd = None if self._state_dicts is None else self._state_dicts["vae"]
+        super().to(device, dtype)
+        if self._vae_fp32:
+            self.upcast_vae()
+        return self
+
+    def _build_extra(self, sd, cf, device, cdt):
+        self.text_encoder_2 = models.CLIPText(sd["text2"], cf["text2"], device, cdt)
+
+    def upcast_vae(self):
+        """run_aug/run_aug.py:224: the VAE decodes in float32.  Before `.to()` it is recorded; after, the decoder is
+        re-packed for the exact-fp32 kernels from the retained VAE state dict."""
+        self._vae_fp32 = True
+        if self.vae is not None and self.vae.dtype != torch.float32:
+            self.vae = models.VAEDecoder(self._vae_sd, self.cfgs["vae"], self.device, torch.float32)
+        return self
+
+    # ---- pieces ------------------------------------------------------------------------
+    def pad_ids_2(self, ids):
+        """tokenizer_2 pads with id 0 ("!") after the first EOS instead of repeating EOS."""
+        ids = np.array(ids, np.int64, copy=True)
+        eos = ids.max(axis=1, keepdims=True)
+        first = (ids == eos).argmax(axis=1)
+        for r in range(ids.shape[0]):
+            ids[r, first[r] + 1:] = self.cfgs["text2"].get("pad_id", 0)
+        return ids
+
+    def encode_prompts_xl(self, ids1, ids2):
+        """-> (context [B,77,ctx1+ctx2], pooled [B, proj] fp32)."""
+        self._need_device()
+        t = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(self.device)   # noqa: E731
+        h1, _ = self.text_encoder.forward(t(ids1), penultimate=True)
+        h2, pooled = self.text_encoder_2.forward(t(ids2), penultimate=True)
+        return torch.cat([h1, h2], -1).contiguous(), pooled.float()
+
+    @torch.no_grad()
+    def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps, guidance_scale=0.0,
+                       controlnet_conditioning_scale=0.75, return_latents=False, latents_on_device=False,
+                       prompt_ids_2=None, **unused):
+        """Same contract as the SD-1.5 form; `negative_ids` is ignored (no CFG at the reference's operating point) and
+        `prompt_ids_2` defaults to the tokenizer_2 padding of `prompt_ids`."""
+        self._need_device()
+        if guidance_scale > 1.0:
+            raise NotImplementedError("the reference runs sd_xl-turbo with guidance_scale 0 (run_aug/run_aug.py:568); "
+                                      "CFG for SDXL is not built")
+        dev, dt = self.device, self.dtype
+        ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
+        ctrl = ctrl.to(dev).contiguous()
+        b, hh, ww, _ = ctrl.shape
+        if hh % 8 or ww % 8:
+            raise ValueError("control image sides must be multiples of 8")
+        want = (b, hh // 8, ww // 8, 8) if latents_on_device else (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
+        if tuple(latents.shape) != want:
+            raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")
+        ids1 = np.asarray(prompt_ids.cpu() if torch.is_tensor(prompt_ids) else prompt_ids)
+        ids2 = self.pad_ids_2(ids1) if prompt_ids_2 is None else prompt_ids_2
+        ctx, pooled = self.encode_prompts_xl(ids1, ids2)
+        time_ids = [[hh, ww, 0, 0, hh, ww]] * b            # original_size + crops_coords_top_left + target_size
+        cond = ops.u8_to_act(ctrl, dt)
+        cemb = self.controlnet.cond_embedding(cond)
+        x = (latents if latents_on_device else self.latents_to_device(latents)).contiguous()
+        sch = self.scheduler
+        ts = sch.set_timesteps(num_inference_steps)
+        for net in (self.unet, self.controlnet):
+            net.prepare_context(ctx)
+            net.prepare_timesteps(ts, (pooled, time_ids))
+        eps = torch.zeros_like(x)
+        nc, hw = self.cfgs["unet"]["out_channels"], (hh // 8) * (ww // 8)
+        for i, t in enumerate(ts):
+            mid, skips = self.unet.encode(x, i)
+            skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
+            self.unet.decode(mid2, skips2, i, out=eps)
+            ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))
+        z = ops.scale(x, 1.0 / self.cfgs["vae"]["scaling_factor"])
+        if self.vae.dtype != z.dtype:
+            z = z.to(self.vae.dtype)                      # upcast_vae(): latents follow the VAE dtype
+        img = self.vae.decode(z)
+        out = ops.act_to_u8(img)
+        if return_latents:
+            return out, x, img
+        return out
+
+    def __call__(self, prompt=None, image=None, num_inference_steps=50, generator=None, guidance_scale=5.0,
+                 negative_prompt=None, controlnet_conditioning_scale=1.0, **unused):
+        self._need_device()
+        if image is None or prompt is None:
+            raise ValueError("`prompt` and `image` (the control image) are required")
+        ctrl = np.asarray(image.convert("RGB") if isinstance(image, Image.Image) else image, dtype=np.uint8)
+        if ctrl.ndim != 3 or ctrl.shape[2] != 3:
+            raise ValueError("control image must be RGB")
+        hh, ww = ctrl.shape[:2]
+        if generator is not None and generator.device.type != "cpu":
+            raise NotImplementedError("the reference passes the global CPU generator (run_aug/run_aug.py:324)")
+        lat = torch.randn((1, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8), generator=generator, dtype=self.noise_dtype)
+        ids1 = self.tokenizer(str(prompt))
+        ids2 = self.pad_ids_2(self.tokenizer_2(str(prompt)))
+        out = self.generate_batch(ids1, None, ctrl[None], lat, num_inference_steps, guidance_scale,
+                                  controlnet_conditioning_scale, prompt_ids_2=ids2)
         arr = out.cpu().numpy()
         return PipelineOutput([Image.fromarray(a) for a in arr], None)

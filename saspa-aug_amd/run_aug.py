@@ -143,8 +143,9 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
     SaSPA configuration for planes and the BASELINE metric).  `use_compile` is accepted and
     ignored: the reference's torch.compile(reduce-overhead) has no counterpart, the kernels are
     launched directly."""
-    from .config import BLIP_DIFFUSION, SD15
-    from .pipeline import BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline
+    from .config import BLIP_DIFFUSION, SD15, SDXL_TURBO
+    from .pipeline import (BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline,
+                           StableDiffusionXLControlNetPipeline)
     from .scheduler import DDIMScheduler
     assert base_model in BASE_MODEL_DICT.keys()
     assert controlnet in CONTROLNET_DICT_SD.keys() or controlnet in CONTROLNET_DICT_SD_XL.keys() or controlnet is None
@@ -159,12 +160,30 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
             return BlipDiffusionControlNetPipeline.from_pretrained(os.path.join(weights_dir, BASE_MODEL_DICT["blip_diffusion-controlnet"]), cfgs)
         logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
         return BlipDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0)
-    if base_model != "sd_v1.5" or controlnet != "canny" or SDEdit:
-        raise NotImplementedError(
-            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 and blip_diffusion with the canny ControlNet are built; "
-            "SDXL-Turbo is SURVEY 8(a) row a9, SDEdit / HED / ip2p / blip_diffusion-edit are baseline branches")
     if sampler != "ddim":
         raise NotImplementedError("UniPC sampler (SURVEY 8(f) f4)")
+    if base_model == "sd_xl-turbo" and controlnet == "canny" and not SDEdit:
+        # run_aug/run_aug.py:185-201: ControlNetModel(diffusers/controlnet-canny-sdxl-1.0) + sdxl-vae-fp16-fix +
+        # StableDiffusionXLControlNetPipeline(stabilityai/sdxl-turbo); :217-228 DDIM from the pipeline's scheduler
+        # config (twice), upcast_vae()
+        cfgs = cfgs or SDXL_TURBO
+        if state_dicts is not None:
+            pipe = StableDiffusionXLControlNetPipeline(state_dicts, cfgs)
+        elif weights_dir:
+            vae_dir = os.path.join(weights_dir, "madebyollin/sdxl-vae-fp16-fix")
+            pipe = StableDiffusionXLControlNetPipeline.from_pretrained(
+                os.path.join(weights_dir, BASE_MODEL_DICT[base_model]), os.path.join(weights_dir, CONTROLNET_DICT_SD_XL[controlnet]),
+                vae_dir if os.path.isdir(vae_dir) else None, cfgs)
+        else:
+            logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
+            pipe = StableDiffusionXLControlNetPipeline.from_synthetic(cfgs, seed=0)
+        pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+        pipe.upcast_vae()
+        return pipe
+    if base_model != "sd_v1.5" or controlnet != "canny" or SDEdit:
+        raise NotImplementedError(
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5, blip_diffusion and sd_xl-turbo with the canny ControlNet "
+            "are built; SDEdit / HED / ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are baseline branches")
     cfgs = cfgs or SD15
     if state_dicts is not None:
         pipe = StableDiffusionControlNetPipeline(state_dicts, cfgs)

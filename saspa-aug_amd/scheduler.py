@@ -13,6 +13,17 @@ SD15_SCHEDULER_CONFIG = dict(
 )
 
 
+# stabilityai/sdxl-turbo scheduler/scheduler_config.json (EulerAncestralDiscreteScheduler) as seen by
+# `DDIMScheduler.from_config` at run_aug/run_aug.py:228: the keys DDIM understands are kept -- "trailing" spacing,
+# the SD beta schedule, and the SDXL repos' leftover clip_sample=false / set_alpha_to_one=false.  Recalled (no
+# network here): parity unpinned.
+SDXL_TURBO_SCHEDULER_CONFIG = dict(
+    num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+    steps_offset=1, set_alpha_to_one=False, clip_sample=False, prediction_type="epsilon",
+    timestep_spacing="trailing",
+)
+
+
 class DDIMScheduler:
     def __init__(self, **config):
         self.config = dict(SD15_SCHEDULER_CONFIG)

@@ -26,19 +26,26 @@ def _resnet(spec, pfx, cin, cout, temb):
         spec += [(pfx + ".conv_shortcut.weight", (cout, cin, 1, 1), "w"), (pfx + ".conv_shortcut.bias", (cout,), "bias")]
 
 
-def _transformer(spec, pfx, c, ctx):
+def _transformer(spec, pfx, c, ctx, depth=1, linear_proj=False):
+    pshape = (c, c) if linear_proj else (c, c, 1, 1)
     spec += [(pfx + ".norm.weight", (c,), "gain"), (pfx + ".norm.bias", (c,), "bias"),
-             (pfx + ".proj_in.weight", (c, c, 1, 1), "w"), (pfx + ".proj_in.bias", (c,), "bias")]
-    t = pfx + ".transformer_blocks.0"
-    for n in ("norm1", "norm2", "norm3"):
-        spec += [(f"{t}.{n}.weight", (c,), "gain"), (f"{t}.{n}.bias", (c,), "bias")]
-    for a, kd in (("attn1", c), ("attn2", ctx)):
-        spec += [(f"{t}.{a}.to_q.weight", (c, c), "w"), (f"{t}.{a}.to_k.weight", (c, kd), "w"),
-                 (f"{t}.{a}.to_v.weight", (c, kd), "w"), (f"{t}.{a}.to_out.0.weight", (c, c), "w"),
-                 (f"{t}.{a}.to_out.0.bias", (c,), "bias")]
-    spec += [(f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"), (f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"),
-             (f"{t}.ff.net.2.weight", (c, 4 * c), "w"), (f"{t}.ff.net.2.bias", (c,), "bias")]
-    spec += [(pfx + ".proj_out.weight", (c, c, 1, 1), "w"), (pfx + ".proj_out.bias", (c,), "bias")]
+             (pfx + ".proj_in.weight", pshape, "w"), (pfx + ".proj_in.bias", (c,), "bias")]
+    for d in range(depth):
+        t = f"{pfx}.transformer_blocks.{d}"
+        for n in ("norm1", "norm2", "norm3"):
+            spec += [(f"{t}.{n}.weight", (c,), "gain"), (f"{t}.{n}.bias", (c,), "bias")]
+        for a, kd in (("attn1", c), ("attn2", ctx)):
+            spec += [(f"{t}.{a}.to_q.weight", (c, c), "w"), (f"{t}.{a}.to_k.weight", (c, kd), "w"),
+                     (f"{t}.{a}.to_v.weight", (c, kd), "w"), (f"{t}.{a}.to_out.0.weight", (c, c), "w"),
+                     (f"{t}.{a}.to_out.0.bias", (c,), "bias")]
+        spec += [(f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"), (f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"),
+                 (f"{t}.ff.net.2.weight", (c, 4 * c), "w"), (f"{t}.ff.net.2.bias", (c,), "bias")]
+    spec += [(pfx + ".proj_out.weight", pshape, "w"), (pfx + ".proj_out.bias", (c,), "bias")]
+
+
+def level_depth(cfg, i):
+    """Transformer depth of level i (SD-1.5: 1 everywhere; SDXL: transformer_layers_per_block)."""
+    return cfg["depth"][i] if "depth" in cfg else 1
 
 
 def _encoder(spec, cfg):
@@ -47,13 +54,19 @@ def _encoder(spec, cfg):
     spec += [("conv_in.weight", (bo[0], cfg["in_channels"], 3, 3), "w"), ("conv_in.bias", (bo[0],), "bias"),
              ("time_embedding.linear_1.weight", (temb, bo[0]), "w"), ("time_embedding.linear_1.bias", (temb,), "bias"),
              ("time_embedding.linear_2.weight", (temb, temb), "w"), ("time_embedding.linear_2.bias", (temb,), "bias")]
+    if "add_embed" in cfg:   # SDXL addition_embed_type "text_time"
+        ae = cfg["add_embed"]
+        ain = ae["n_ids"] * ae["time_dim"] + ae["pooled_dim"]
+        spec += [("add_embedding.linear_1.weight", (temb, ain), "w"), ("add_embedding.linear_1.bias", (temb,), "bias"),
+                 ("add_embedding.linear_2.weight", (temb, temb), "w"), ("add_embedding.linear_2.bias", (temb,), "bias")]
+    lp = cfg.get("linear_proj", False)
     cin = bo[0]
     skip_ch = [bo[0]]
     for i, c in enumerate(bo):
         for j in range(cfg["layers"]):
             _resnet(spec, f"down_blocks.{i}.resnets.{j}", cin, c, temb)
             if cfg["attn"][i]:
-                _transformer(spec, f"down_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"])
+                _transformer(spec, f"down_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"], level_depth(cfg, i), lp)
             cin = c
             skip_ch.append(c)
         if i != len(bo) - 1:
@@ -61,7 +74,7 @@ def _encoder(spec, cfg):
                      (f"down_blocks.{i}.downsamplers.0.conv.bias", (c,), "bias")]
             skip_ch.append(c)
     _resnet(spec, "mid_block.resnets.0", cin, cin, temb)
-    _transformer(spec, "mid_block.attentions.0", cin, cfg["ctx_dim"])
+    _transformer(spec, "mid_block.attentions.0", cin, cfg["ctx_dim"], level_depth(cfg, len(bo) - 1), lp)
     _resnet(spec, "mid_block.resnets.1", cin, cin, temb)
     return skip_ch
 
@@ -78,7 +91,8 @@ def unet_spec(cfg):
             skip = skip_ch.pop()
             _resnet(spec, f"up_blocks.{i}.resnets.{j}", prev + skip, c, cfg["temb_dim"])
             if rev_attn[i]:
-                _transformer(spec, f"up_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"])
+                _transformer(spec, f"up_blocks.{i}.attentions.{j}", c, cfg["ctx_dim"], level_depth(cfg, len(bo) - 1 - i),
+                             cfg.get("linear_proj", False))
             prev = c
         if i != len(bo) - 1:
             spec += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (c, c, 3, 3), "w"),
@@ -146,6 +160,8 @@ def clip_text_spec(cfg):
                  (f"{lp}.mlp.fc2.weight", (w, cfg["mlp"]), "w"), (f"{lp}.mlp.fc2.bias", (w,), "bias"),
                  (f"{lp}.layer_norm2.weight", (w,), "gain"), (f"{lp}.layer_norm2.bias", (w,), "bias")]
     spec += [("text_model.final_layer_norm.weight", (w,), "gain"), ("text_model.final_layer_norm.bias", (w,), "bias")]
+    if "proj_dim" in cfg:    # CLIPTextModelWithProjection (SDXL text_encoder_2)
+        spec += [("text_projection.weight", (cfg["proj_dim"], w), "w")]
     return spec
 
 
@@ -197,7 +213,8 @@ def blip2_qformer_spec(cfg):
     return spec
 
 
-SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec, qformer=blip2_qformer_spec)
+SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec, text2=clip_text_spec,
+             qformer=blip2_qformer_spec)
 
 
 def synth_state_dict(kind, cfg, seed=0):
@@ -221,7 +238,7 @@ def synth_state_dict(kind, cfg, seed=0):
 
 
 def synth_family(cfgs, seed=0):
-    kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ())
+    kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ()) + (("text2",) if "text2" in cfgs else ())
     return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
 
 

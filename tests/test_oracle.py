@@ -100,3 +100,80 @@ def test_param_counts_match_public_figures():
     n = {k: sum(torch.Size(s).numel() for _, s, _ in W.SPECS[k](CFG.SD15[k])) for k in CFG.SD15}
     assert n == dict(unet=859520964, controlnet=361279120, vae=49490199, text=123060480)
     assert CFG.SD15_UNET == OM.SD15_UNET and CFG.SD15_CONTROLNET == OM.SD15_CONTROLNET and CFG.SD15_VAE == OM.SD15_VAE
+
+
+# ---- SDXL-Turbo ------------------------------------------------------------------------------
+def test_clip_penultimate_and_projection_match_transformers():
+    """SDXL encode_prompt reads hidden_states[-2] of both towers and text_embeds of CLIPTextModelWithProjection
+    (erf-GELU, pad id 0 after the EOS): check both against the independent transformers implementation."""
+    tr = pytest.importorskip("transformers")
+    cfg = dict(vocab=1000, width=64, layers=3, heads=4, mlp=256, max_pos=77, act="gelu", proj_dim=48, pad_id=0)
+    hf_cfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=3,
+                               num_attention_heads=4, max_position_embeddings=77, hidden_act="gelu", projection_dim=48,
+                               layer_norm_eps=1e-5, bos_token_id=998, eos_token_id=999, pad_token_id=0)
+    model = tr.CLIPTextModelWithProjection(hf_cfg).eval()
+    sd = W.synth_state_dict("text2", cfg, seed=6)
+    hf_sd = sd
+    if not any(k.startswith("text_model.") for k in model.state_dict()):
+        hf_sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in sd.items()}
+    missing = model.load_state_dict(hf_sd, strict=False)
+    assert not [k for k in missing.missing_keys if "position_ids" not in k], missing
+    assert not missing.unexpected_keys
+    rs = np.random.RandomState(0)
+    ids = torch.from_numpy(rs.randint(1, 998, (2, 77)))
+    ids[:, 0] = 998
+    ids[0, 9], ids[1, 30] = 999, 999
+    ids[0, 10:], ids[1, 31:] = 0, 0
+    with torch.no_grad():
+        out = model(input_ids=ids, output_hidden_states=True)
+        h2, pooled = OM.clip_text_forward(sd, cfg, ids, penultimate=True)
+    assert (out.hidden_states[-2] - h2).abs().max().item() < 1e-4
+    assert (out.text_embeds - pooled).abs().max().item() < 1e-4
+
+
+def test_sdxl_param_counts_match_public_figures():
+    from saspa_aug_amd import config as CFG
+    n = {k: sum(torch.Size(s).numel() for _, s, _ in W.SPECS[k](CFG.SDXL_TURBO[k])) for k in CFG.SDXL_TURBO}
+    # public figures: SDXL UNet 2 567 463 684, OpenCLIP bigG text tower with projection 694 659 840, CLIP-L 123 060 480
+    assert n["unet"] == 2567463684 and n["text2"] == 694659840 and n["text"] == 123060480
+    assert n["controlnet"] == 1251014160 and n["vae"] == 49490199
+    keys = {name for name, _, _ in W.SPECS["unet"](CFG.SDXL_UNET)}
+    assert "down_blocks.2.attentions.1.transformer_blocks.9.attn2.to_k.weight" in keys          # depth 10 at level 2
+    assert "down_blocks.0.attentions.0.norm.weight" not in keys                                  # DownBlock2D at level 0
+    assert "up_blocks.0.attentions.2.transformer_blocks.9.ff.net.2.weight" in keys
+    assert "add_embedding.linear_1.weight" in keys and "mid_block.attentions.0.proj_in.weight" in keys
+
+
+def test_ddim_trailing_timesteps_of_the_sdxl_turbo_config():
+    from saspa_aug_amd.scheduler import SDXL_TURBO_SCHEDULER_CONFIG, DDIMScheduler
+    s = DDIMScheduler.from_config(SDXL_TURBO_SCHEDULER_CONFIG)
+    assert list(s.set_timesteps(2)) == [999, 499] and list(s.set_timesteps(4)) == [999, 749, 499, 249]
+    o = OP.DDIM(spacing="trailing")
+    assert list(o.set_timesteps(2)) == [999, 499]
+    # last step lands on alphas_cumprod[0] (set_alpha_to_one=False): prev_t = 499 - 500 < 0
+    a_t, a_p = o.coefficients(499)
+    assert a_p == o.alphas_cumprod[0] and a_t == o.alphas_cumprod[499]
+    s.set_timesteps(2)
+    c = s.step_coefficients(499)
+    assert abs(c[2] - float(o.alphas_cumprod[0] ** 0.5)) < 1e-7
+
+
+def test_sdxl_oracle_pipeline_runs_and_added_conditioning_matters():
+    from saspa_aug_amd import config as CFG
+    cfgs = CFG.tiny_xl()
+    fam = W.synth_family(cfgs, seed=3)
+    ids1 = torch.from_numpy(np.random.RandomState(1).randint(0, 500, (1, 77)))
+    ids1[0, 0], ids1[0, 12:] = 510, 511
+    ids2 = ids1.clone()
+    ids2[0, 13:] = 0
+    ctrl = (np.random.RandomState(0).rand(64, 64, 3) > 0.9).astype(np.uint8) * 255
+    lat = torch.randn((1, 4, 8, 8), generator=torch.manual_seed(1))
+    out = OP.sdxl_controlnet_pipeline(fam, cfgs, ids1, ids2, ctrl, lat, 2)
+    assert out.shape == (1, 64, 64, 3) and out.dtype == np.uint8
+    # the text_time embedding enters every resnet: another size id changes the UNet output
+    x = torch.randn(1, 4, 8, 8, generator=torch.manual_seed(2))
+    ctx = torch.randn(1, 77, cfgs["unet"]["ctx_dim"], generator=torch.manual_seed(3))
+    pooled = torch.randn(1, cfgs["unet"]["add_embed"]["pooled_dim"], generator=torch.manual_seed(4))
+    a = OM.unet_forward(fam["unet"], cfgs["unet"], x, 499, ctx, added=dict(text_embeds=pooled, time_ids=torch.tensor([[64., 64, 0, 0, 64, 64]])))
+    b = OM.unet_forward(fam["unet"], cfgs["unet"], x, 499, ctx, added=dict(text_embeds=pooled, time_ids=torch.tensor([[96., 64, 0, 0, 96, 64]])))
+    assert (a - b).abs().max() > 1e-4

@@ -203,6 +203,23 @@ int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, long long n
 int saspa_canny(const uint8_t* src, uint8_t* dst, uint8_t* work, int n, int H, int W, int low, int high,
                 void* stream);
 
+/* ---- image pre-processing of the CLIP image front-ends (integer exact) ----------
+ * One separable pass of Pillow's antialiased resampling for 8-bit channels (ImagingResample, the arithmetic behind
+ * PIL.Image.resize that transformers' CLIPImageProcessor -- the feature_extractor of StableDiffusionSafetyChecker --
+ * and BlipImageProcessor call; SURVEY 8a: a7.9, a8):
+ *   dst[(o*out_len + t)*inner + i] = clip8(((1 << 21) + sum_{k < bounds[t][1]} src[(o*in_len + bounds[t][0] + k)*inner + i]
+ *                                           * coeffs[t][k]) >> 22)
+ * bounds [out_len][2] = (first input sample, sample count <= ksize), coeffs [out_len][ksize] = the filter weights in
+ * 22-bit fixed point -- both DEVICE int32 tables prepared by the host (they depend only on the sizes).  A horizontal
+ * pass over [n][H][W][3] is outer = n*H, inner = 3; a vertical pass is outer = n, inner = W*3.  A crop is folded in by
+ * passing only the table rows of the wanted outputs. */
+int saspa_resample_u8(const uint8_t* src, uint8_t* dst, long long outer, int in_len, int out_len, int inner,
+                      const int* bounds, const int* coeffs, int ksize, void* stream);
+/* u8 RGB [npix][3] -> [npix][8] activations ((x/255) - mean[c]) / std[c], pad channels zero
+ * (CLIPImageProcessor rescale + normalize; SURVEY 8a: a7.9) */
+int saspa_u8_to_act_norm(int dtype, const uint8_t* src, void* dst, long long npix, float mean0, float mean1, float mean2,
+                         float std0, float std1, float std2, void* stream);
+
 /* library self-description */
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);

@@ -137,9 +137,24 @@ def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents,
         x = sch.step(eps, t, x)
     img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
     out = postprocess(img)
+    if "safety" in weights and "safety" in cfgs:
+        out = run_safety_checker(weights["safety"], cfgs["safety"], out)[0]
     if return_latents:
         return out, x, img
     return out
+
+
+def run_safety_checker(sd, cfg, images_u8):
+    """StableDiffusionControlNetPipeline.run_safety_checker + the checker's black-out: u8 [B,H,W,3] ->
+    (u8 images with flagged ones zeroed, flags)."""
+    from . import image_ops as IO
+    px = torch.stack([IO.clip_image_preprocess(im, cfg["image_size"]) for im in images_u8])
+    flags, _, _ = IO.safety_checker_forward(sd, cfg, px)
+    out = images_u8.copy()
+    for i, f in enumerate(flags):
+        if f:
+            out[i] = 0
+    return out, flags
 
 
 def build_blip_prompt(prompt, tgt_subject, prompt_strength=1.0, prompt_reps=20):

@@ -66,6 +66,8 @@ SYMBOLS = {
     "saspa_u8_to_act": (_I, [_I, _P, _P, _LL, _P]),
     "saspa_act_to_u8": (_I, [_I, _P, _I, _P, _LL, _P]),
     "saspa_canny": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "saspa_resample_u8": (_I, [_P, _P, _LL, _I, _I, _I, _P, _P, _I, _P]),
+    "saspa_u8_to_act_norm": (_I, [_I, _P, _P, _LL, _F, _F, _F, _F, _F, _F, _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

@@ -16,7 +16,13 @@ SD15_VAE = dict(latent_channels=4, out_channels=3, block_out=(128, 256, 512, 512
 # openai/clip-vit-large-patch14 text tower (text_encoder/config.json)
 CLIP_L = dict(vocab=49408, width=768, layers=12, heads=12, mlp=3072, max_pos=77)
 
-SD15 = dict(unet=SD15_UNET, controlnet=SD15_CONTROLNET, vae=SD15_VAE, text=CLIP_L)
+# runwayml/stable-diffusion-v1-5 : safety_checker/config.json (StableDiffusionSafetyChecker = CLIP ViT-L/14 vision tower
+# + visual_projection 1024 -> 768 + 17 concept / 3 special-care embeddings with thresholds) and feature_extractor
+# (CLIPImageProcessor: shortest edge 224 bicubic, centre crop 224, CLIP mean / std).  The reference never disables it
+# (run_aug/run_aug.py:185-207).
+SAFETY_CHECKER = dict(image_size=224, patch=14, width=1024, layers=24, heads=16, mlp=4096, proj_dim=768, n_concepts=17,
+                      n_special=3)
+SD15 = dict(unet=SD15_UNET, controlnet=SD15_CONTROLNET, vae=SD15_VAE, text=CLIP_L, safety=SAFETY_CHECKER)
 
 # stabilityai/sdxl-turbo (= SDXL-base architecture) : unet/config.json.  Three levels, no attention at level 0,
 # transformer_layers_per_block (1, 2, 10) -> "depth" (level 0 unused), attention_head_dim (5, 10, 20) = heads per
@@ -48,7 +54,7 @@ BLIP2_QFORMER = dict(
 )
 BLIP_IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
 BLIP_IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
-BLIP_DIFFUSION = dict(SD15, qformer=BLIP2_QFORMER, ctx_begin_pos=2)
+BLIP_DIFFUSION = dict({k: v for k, v in SD15.items() if k != "safety"}, qformer=BLIP2_QFORMER, ctx_begin_pos=2)
 
 
 def tiny_xl(width=32, ctx1=32, ctx2=64, groups=8, vae_width=16):
@@ -77,4 +83,5 @@ def tiny(width=32, ctx=64, groups=8, heads=4, vae_width=16):
     qformer = dict(image_size=56, patch=14, vis_width=64, vis_layers=2, vis_heads=4, vis_mlp=128, vis_eps=1e-5,
                    width=ctx, layers=2, heads=4, mlp=2 * ctx, cross_freq=1, num_query=16, vocab=512, max_pos=32, eps=1e-12,
                    proj_hidden=2 * ctx, out_dim=ctx)
-    return dict(unet=unet, controlnet=cn, vae=vae, text=text, qformer=qformer, ctx_begin_pos=2)
+    safety = dict(image_size=56, patch=14, width=64, layers=2, heads=4, mlp=128, proj_dim=48, n_concepts=17, n_special=3)
+    return dict(unet=unet, controlnet=cn, vae=vae, text=text, qformer=qformer, ctx_begin_pos=2, safety=safety)

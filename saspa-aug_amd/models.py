@@ -19,6 +19,7 @@ Layout decisions (MI355X-first, not a translation of diffusers' NCHW modules):
 Semantics follow [upstream] diffusers 0.32.2 as listed in SURVEY.md 3.2 / 8(a7)."""
 import math
 
+import numpy as np
 import torch
 
 from . import ops
@@ -463,7 +464,18 @@ class VAEDecoder:
         return ops.linear(o, p[a + ".o.w"], p[a + ".o.b"], residual=x.view(b, n, c)).view(b, hh, ww, c)
 
     def decode(self, z):
-        """z: [B,h,w,8] latents ALREADY divided by the scaling factor -> [B,8h,8w,8] (3 live)."""
+        """z: [B,h,w,8] latents ALREADY divided by the scaling factor -> [B,8h,8w,8] (3 live).  The kernels address
+        an operand with 32-bit byte offsets (< 2 GiB): the widest full-resolution activation (block_out[1] channels)
+        bounds the images per launch sequence -- 8 at 512x512 in bf16, 3 in fp32 (upcast VAE), 1 at 1024x1024 fp32."""
+        b, h, w, _ = z.shape
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        per_img = 64 * h * w * self.cfg["block_out"][min(1, len(self.cfg["block_out"]) - 1)] * esz
+        chunk = max(1, ((1 << 31) - 1) // per_img)
+        if b <= chunk:
+            return self._decode(z)
+        return torch.cat([self._decode(z[i:i + chunk].contiguous()) for i in range(0, b, chunk)], 0)
+
+    def _decode(self, z):
         p, cfg = self.p, self.cfg
         h = ops.conv(z, p["post_quant_conv.w"], p["post_quant_conv.b"])
         h = ops.conv(h, p["decoder.conv_in.w"], p["decoder.conv_in.b"], kh=3, kw=3, pad=1)
@@ -548,3 +560,109 @@ class CLIPText:
         rows = x[torch.arange(b, device=x.device), eos].contiguous()    # gather of the EOS rows (data movement)
         rows = ops.layernorm(rows, p["text_model.final_layer_norm.g"], p["text_model.final_layer_norm.b"])
         return hidden2, ops.linear(rows, p["text_projection.w"])
+
+
+class SafetyChecker:
+    """StableDiffusionSafetyChecker: CLIP ViT-L/14 vision tower -> post_layernorm(CLS) ->
+    visual_projection -> cosine similarity against 17 concept / 3 special-care embeddings.  The tower, projection and
+    the (image x concept) similarity GEMM run in the HIP kernels; the thresholding of the 20 scores per image
+    (round(., 3), the 0.01 special-care adjustment) is host control flow exactly as upstream.
+    Patch embedding = one implicit-GEMM conv (14x14 window, stride 14) over the normalised channels-last pixels."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        pk = self.pk = _Packed(sd, dev, dtype)
+        p = self.p = pk.p
+        v = "vision_model.vision_model"
+        w = cfg["width"]
+        pk.conv(v + ".embeddings.patch_embedding")
+        pos = sd[v + ".embeddings.position_embedding.weight"]
+        p["cls_pos"] = (sd[v + ".embeddings.class_embedding"] + pos[0]).to(dev, dtype).reshape(1, 1, w).contiguous()
+        p["patch_pos"] = pos[1:].to(dev, dtype).contiguous()
+        pk.norm(v + ".pre_layrnorm")
+        for i in range(cfg["layers"]):
+            lp = f"{v}.encoder.layers.{i}"
+            a = lp + ".self_attn"
+            p[a + ".qk.w"] = torch.cat([sd[a + ".q_proj.weight"], sd[a + ".k_proj.weight"]], 0).contiguous().to(dev, dtype)
+            p[a + ".qk.b"] = _f32(torch.cat([sd[a + ".q_proj.bias"], sd[a + ".k_proj.bias"]]), dev)
+            p[a + ".v.w"] = sd[a + ".v_proj.weight"].contiguous().to(dev, dtype)
+            wo = sd[a + ".out_proj.weight"]
+            p[a + ".o.w"] = wo.contiguous().to(dev, dtype)
+            p[a + ".o.b"] = _f32(sd[a + ".out_proj.bias"] + wo @ sd[a + ".v_proj.bias"], dev)
+            pk.norm(lp + ".layer_norm1")
+            pk.norm(lp + ".layer_norm2")
+            pk.linear(lp + ".mlp.fc1")
+            pk.linear(lp + ".mlp.fc2")
+        pk.norm(v + ".post_layernorm")
+        # projection + similarity stay fp32 (20 thresholds decide on the third decimal)
+        p["proj.w"] = sd["visual_projection.weight"].contiguous().to(dev, torch.float32)
+        emb = torch.cat([sd["special_care_embeds"], sd["concept_embeds"]], 0)
+        p["embeds_n"] = torch.nn.functional.normalize(emb.float()).contiguous().to(dev)        # constant: unit rows
+        self.special_w = sd["special_care_embeds_weights"].double().numpy()
+        self.concept_w = sd["concept_embeds_weights"].double().numpy()
+        pk.sd = None
+
+    def image_embeds(self, pixels):
+        """[B,S,S,8] normalised channels-last pixels -> fp32 [B, proj_dim]."""
+        cfg, p = self.cfg, self.p
+        v = "vision_model.vision_model"
+        b = pixels.shape[0]
+        ps, w, heads = cfg["patch"], cfg["width"], cfg["heads"]
+        g = pixels.shape[1] // ps
+        pos = p["patch_pos"].view(1, g, g, w).expand(b, -1, -1, -1).contiguous()
+        tok = ops.conv(pixels, p[v + ".embeddings.patch_embedding.w"], None, kh=ps, kw=ps, stride=ps, pad=0, residual=pos)
+        x = torch.cat([p["cls_pos"].expand(b, -1, -1), tok.view(b, g * g, w)], 1).contiguous()
+        n = x.shape[1]
+        x = ops.layernorm(x, p[v + ".pre_layrnorm.g"], p[v + ".pre_layrnorm.b"])
+        for i in range(cfg["layers"]):
+            lp = f"{v}.encoder.layers.{i}"
+            a = lp + ".self_attn"
+            h = ops.layernorm(x, p[lp + ".layer_norm1.g"], p[lp + ".layer_norm1.b"])
+            qk = ops.linear(h, p[a + ".qk.w"], p[a + ".qk.b"])
+            vt = project_vt(h, p[a + ".v.w"], n)
+            o = attention_core(qk[:, :, :w], qk[:, :, w:], vt, heads, n, n)
+            x = ops.linear(o, p[a + ".o.w"], p[a + ".o.b"], residual=x)
+            h = ops.layernorm(x, p[lp + ".layer_norm2.g"], p[lp + ".layer_norm2.b"])
+            h = ops.activation(ops.linear(h, p[lp + ".mlp.fc1.w"], p[lp + ".mlp.fc1.b"]), ops.ACT_QUICK_GELU)
+            x = ops.linear(h, p[lp + ".mlp.fc2.w"], p[lp + ".mlp.fc2.b"], residual=x)
+        cls = x[:, 0].contiguous()
+        pooled = ops.layernorm(cls, p[v + ".post_layernorm.g"], p[v + ".post_layernorm.b"]).float()
+        return ops.linear(pooled, p["proj.w"])
+
+    def similarity(self, pixels):
+        """-> (dots fp32 [B, n_special + n_concepts] = e . unit(embed_j), special-care columns first; gram fp32 [B, >=B]
+        = e e^T whose diagonal is |e|^2).  Two tiny GEMMs; the division by |e| happens with the thresholding on the host."""
+        e = self.image_embeds(pixels)[:, :self.cfg["proj_dim"]].contiguous()
+        return ops.linear(e, self.p["embeds_n"]), ops.linear(e, e)
+
+    def decide(self, dots, gram):
+        """Upstream's per-image thresholding, on the host (20 numbers per image): cos = dots / |e|, scores rounded to 3
+        decimals, +0.01 once a special-care concept fires -> (flags, concept scores, special scores)."""
+        dots = dots.double().cpu().numpy()
+        norm = np.sqrt(np.diagonal(gram.double().cpu().numpy()[:, :dots.shape[0]]))
+        ns, ncp = len(self.special_w), len(self.concept_w)
+        cos = dots[:, :ns + ncp] / norm[:, None]
+        flags, cs, ss = [], [], []
+        for i in range(cos.shape[0]):
+            adj = 0.0
+            s_scores = [round(float(cos[i, j] - self.special_w[j] + adj), 3) for j in range(ns)]
+            if any(v > 0 for v in s_scores):
+                adj = 0.01
+            c_scores = [round(float(cos[i, ns + j] - self.concept_w[j] + adj), 3) for j in range(ncp)]
+            flags.append(any(v > 0 for v in c_scores))
+            cs.append(c_scores)
+            ss.append(s_scores)
+        return flags, cs, ss
+
+    @torch.no_grad()
+    def forward(self, images_u8):
+        """device u8 [B,H,W,3] decoded images -> (images with flagged ones blacked out, has_nsfw list)."""
+        from .imageproc import clip_image_preprocess
+        px = clip_image_preprocess(images_u8, self.dtype, self.cfg["image_size"])
+        flags, _, _ = self.decide(*self.similarity(px))
+        if any(flags):
+            images_u8 = images_u8.clone()
+            for i, f in enumerate(flags):
+                if f:
+                    images_u8[i].zero_()           # upstream: black image
+        return images_u8, flags

@@ -44,6 +44,8 @@ class StableDiffusionControlNetPipeline:
         self.dtype = None
         self.noise_dtype = None
         self.unet = self.controlnet = self.vae = self.text_encoder = None
+        self.safety_checker = None        # built by .to() when the family ships one; assign None to disable (diffusers idiom)
+        self.last_nsfw = None
         self._neg_cache = {}
 
     # ---- construction -------------------------------------------------------------------
@@ -68,6 +70,9 @@ class StableDiffusionControlNetPipeline:
             text=f(os.path.join(base_dir, "text_encoder"), "model.safetensors", "model.fp16.safetensors"),
             controlnet=f(controlnet_dir, "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"),
         )
+        sc = os.path.join(base_dir, "safety_checker")
+        if "safety" in cfgs and os.path.isdir(sc):
+            sds["safety"] = f(sc, "model.safetensors", "model.fp16.safetensors")
         return cls(sds, cfgs, tokenizer=make_tokenizer(os.path.join(base_dir, "tokenizer"), cfgs["text"]["vocab"]))
 
     def to(self, device, dtype=None):
@@ -96,10 +101,18 @@ class StableDiffusionControlNetPipeline:
         return self
 
     def _build_extra(self, sd, cf, device, cdt):
-        pass
+        # StableDiffusionSafetyChecker of the SD-1.5 repo: the reference never passes safety_checker=None
+        if "safety" in sd and "safety" in cf:
+            self.safety_checker = models.SafetyChecker(sd["safety"], cf["safety"], device, cdt)
 
     def upcast_vae(self):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
         return self
+
+    def run_safety_checker(self, images_u8):
+        """device u8 [B,H,W,3] -> (images with flagged ones replaced by black, has_nsfw_concept list | None)."""
+        if self.safety_checker is None:
+            return images_u8, None
+        return self.safety_checker.forward(images_u8)
 
     # ---- pieces ------------------------------------------------------------------------
     def _need_device(self):
@@ -198,7 +211,7 @@ class StableDiffusionControlNetPipeline:
         self._sample(x2, b, h8 * w8, ctx, cemb2, num_inference_steps, guidance_scale, controlnet_conditioning_scale)
         z = ops.scale(x2[:b], 1.0 / self.cfgs["vae"]["scaling_factor"])
         img = self.vae.decode(z)
-        out = ops.act_to_u8(img)
+        out, self.last_nsfw = self.run_safety_checker(ops.act_to_u8(img))
         if return_latents:
             return out, x2[:b], img
         return out
@@ -222,7 +235,7 @@ class StableDiffusionControlNetPipeline:
         out = self.generate_batch(ids, neg, ctrl[None], lat, num_inference_steps, guidance_scale,
                                   controlnet_conditioning_scale)
         arr = out.cpu().numpy()
-        return PipelineOutput([Image.fromarray(a) for a in arr], [False] * len(arr))
+        return PipelineOutput([Image.fromarray(a) for a in arr], self.last_nsfw)
 
 
 class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
@@ -266,7 +279,7 @@ class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
 
     def _build_extra(self, sd, cf, device, cdt):
         from .blip import Blip2QFormer
-        self.qformer = Blip2QFormer(sd["qformer"], cf["qformer"], device, cdt)
+        self.qformer = Blip2QFormer(sd["qformer"], cf["qformer"], device, cdt)      # (this pipeline has no safety checker)
 
     # ---- pieces ------------------------------------------------------------------------
     @staticmethod

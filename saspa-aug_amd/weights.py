@@ -213,7 +213,33 @@ def blip2_qformer_spec(cfg):
     return spec
 
 
-SPECS = dict(unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec, text2=clip_text_spec,
+def safety_checker_spec(cfg):
+    """StableDiffusionSafetyChecker state dict (diffusers key names; "pre_layrnorm" is the checkpoint's spelling)."""
+    w = cfg["width"]
+    npos = (cfg["image_size"] // cfg["patch"]) ** 2 + 1
+    v = "vision_model.vision_model"
+    spec = [(v + ".embeddings.class_embedding", (w,), "embed"),
+            (v + ".embeddings.patch_embedding.weight", (w, 3, cfg["patch"], cfg["patch"]), "w"),
+            (v + ".embeddings.position_embedding.weight", (npos, w), "embed"),
+            (v + ".pre_layrnorm.weight", (w,), "gain"), (v + ".pre_layrnorm.bias", (w,), "bias")]
+    for i in range(cfg["layers"]):
+        lp = f"{v}.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec += [(f"{lp}.self_attn.{n}.weight", (w, w), "w"), (f"{lp}.self_attn.{n}.bias", (w,), "bias")]
+        spec += [(f"{lp}.layer_norm1.weight", (w,), "gain"), (f"{lp}.layer_norm1.bias", (w,), "bias"),
+                 (f"{lp}.mlp.fc1.weight", (cfg["mlp"], w), "w"), (f"{lp}.mlp.fc1.bias", (cfg["mlp"],), "bias"),
+                 (f"{lp}.mlp.fc2.weight", (w, cfg["mlp"]), "w"), (f"{lp}.mlp.fc2.bias", (w,), "bias"),
+                 (f"{lp}.layer_norm2.weight", (w,), "gain"), (f"{lp}.layer_norm2.bias", (w,), "bias")]
+    spec += [(v + ".post_layernorm.weight", (w,), "gain"), (v + ".post_layernorm.bias", (w,), "bias"),
+             ("visual_projection.weight", (cfg["proj_dim"], w), "w"),
+             ("concept_embeds", (cfg["n_concepts"], cfg["proj_dim"]), "embed"),
+             ("special_care_embeds", (cfg["n_special"], cfg["proj_dim"]), "embed"),
+             ("concept_embeds_weights", (cfg["n_concepts"],), "thresh"),
+             ("special_care_embeds_weights", (cfg["n_special"],), "thresh")]
+    return spec
+
+
+SPECS = dict(safety=safety_checker_spec, unet=unet_spec, controlnet=controlnet_spec, vae=vae_decoder_spec, text=clip_text_spec, text2=clip_text_spec,
              qformer=blip2_qformer_spec)
 
 
@@ -231,6 +257,10 @@ def synth_state_dict(kind, cfg, seed=0):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif k == "bias":
             t = 0.05 * torch.randn(shape, generator=g)
+        elif k == "thresh":
+            # cosine thresholds of the safety checker (the real ones lie around 0.18-0.3): 6 sigma of the cosine of two
+            # random proj_dim-vectors (0.217 at 768) so that random weights never flag an image by accident
+            t = 6.0 / math.sqrt(cfg["proj_dim"]) + 0.01 * torch.randn(shape, generator=g)
         else:  # embeddings
             t = 0.5 * torch.randn(shape, generator=g)
         sd[name] = t
@@ -238,7 +268,8 @@ def synth_state_dict(kind, cfg, seed=0):
 
 
 def synth_family(cfgs, seed=0):
-    kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ()) + (("text2",) if "text2" in cfgs else ())
+    kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ()) + \
+        (("text2",) if "text2" in cfgs else ()) + (("safety",) if "safety" in cfgs else ())
     return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
 
 

@@ -197,8 +197,9 @@ int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, long long n
 
 /* ---- Canny edge extractor (integer exact vs cv2.Canny, aperture 3, L1) ------
  * src: u8 [n][H][W][3]; dst: u8 [n][H][W][3] in {0,255} (HWC3 replicated);
- * work: 8*n*H*W bytes of scratch.  The hysteresis bitmaps of one image live in one
- * CU's LDS: 2*H*ceil(W/32)*4 bytes must fit 160 KiB (e.g. 512x1280), else SASPA_ERANGE.
+ * work: 8*n*H*W bytes of scratch.  The hysteresis bitmaps of one image (2*H*ceil(W/32)*4 bytes)
+ * live in one CU's LDS when they fit 160 KiB (up to e.g. 512x1280); larger images (1024x1024)
+ * keep them in the tail of `work` (W >= 64 required there, else SASPA_ERANGE).
  * Replaces all_utils/utils.py:81-99 CannyDetector/preprocess_canny (a6). */
 int saspa_canny(const uint8_t* src, uint8_t* dst, uint8_t* work, int n, int H, int W, int low, int high,
                 void* stream);

@@ -19,10 +19,13 @@
 
 namespace {
 
-template <int KS, int NB, bool ONES, int KT>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
-  // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key
+template <int KS, int NB, bool ONES, int KT, int NBUF>
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const SaspaAttnParams p) {
+  // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key.
+  // NBUF = LDS tile buffers.  2: the next tile is written into the other buffer at the END of an iteration, so one
+  // barrier per tile and the LDS stores are off the barrier-to-barrier path; 1: store between two barriers.
   constexpr int NKB = KT / 32;               // 32-key blocks of S^T per tile
+  constexpr int NS = 2 * NKB;                // 16-key PV steps per tile
   constexpr int VCH = KT / 8;                // 16-byte chunks per V^T row
   // ONES: D < 32*NB, so V^T row D is a spare MFMA row; it is filled with ones and the PV
   // MFMA then accumulates the softmax denominator there (no VALU row-sum in the loop).
@@ -32,11 +35,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   constexpr int VROW = KT * 2 + 8;           // bytes; (VROW/8) odd -> conflict-free ds_read_b64
   constexpr int K_BYTES = KT * KSLOTS * 16;
   constexpr int V_BYTES = DV * VROW;
+  constexpr int BUF_BYTES = K_BYTES + V_BYTES;
   constexpr int NCH_K = (KT * KCH + 255) / 256;
   constexpr int NCH_V = (DV * VCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
-  unsigned char* ksm = smem;
-  unsigned char* vsm = smem + K_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUF_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
   constexpr unsigned kInv = 0x80000000u;
   unsigned koff[NCH_K], voff[NCH_V];
-  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_d[NCH_V], v_kc[NCH_V];
+  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_kc[NCH_V];
 #pragma unroll
   for (int i = 0; i < NCH_K; ++i) {
     const int q = tid + 256 * i;
@@ -81,9 +83,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   for (int i = 0; i < NCH_V; ++i) {
     const int q = tid + 256 * i;
     const int d = q / VCH, kc = q - d * VCH;
-    v_d[i] = d;
     v_kc[i] = kc;
-    v_lds[i] = (q < DV * VCH && d < D) ? d * VROW + kc * 16 : -1;     // rows >= D are written once, below
+    v_lds[i] = (q < DV * VCH && d < D) ? K_BYTES + d * VROW + kc * 16 : -1;     // rows >= D are written once, below
     voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
   }
   // rows D .. DV-1 of the V^T tile never change: ones (denominator row, when ONES) / zeros
@@ -91,9 +92,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     const int d = q / VCH, kc = q - d * VCH;
     if (d >= D) {
       const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
-      u32x2* dst = reinterpret_cast<u32x2*>(vsm + d * VROW + kc * 16);
-      dst[0] = u32x2{fill, fill};
-      dst[1] = u32x2{fill, fill};
+#pragma unroll
+      for (int bi = 0; bi < NBUF; ++bi) {
+        u32x2* dst = reinterpret_cast<u32x2*>(smem + bi * BUF_BYTES + K_BYTES + d * VROW + kc * 16);
+        dst[0] = u32x2{fill, fill};
+        dst[1] = u32x2{fill, fill};
+      }
     }
   }
   u32x4 kreg[NCH_K], vreg[NCH_V];
@@ -114,11 +118,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
       vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
     }
   };
-  auto store_tile = [&](int key0) __attribute__((always_inline)) {
+  auto store_tile = [&](int key0, unsigned char* buf) __attribute__((always_inline)) {
     const bool tail = key0 + KT > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
 #pragma unroll
     for (int i = 0; i < NCH_K; ++i)
-      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
+      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(buf + k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
       if (v_lds[i] >= 0) {
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
             v[e] &= keep;
           }
         }
-        u32x2* dst = reinterpret_cast<u32x2*>(vsm + v_lds[i]);
+        u32x2* dst = reinterpret_cast<u32x2*>(buf + v_lds[i]);
         dst[0] = u32x2{v.x, v.y};
         dst[1] = u32x2{v.z, v.w};
       }
@@ -150,41 +154,86 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 
   const int ntiles = (p.nk + KT - 1) / KT;
   load_tile(0);
+  if (NBUF == 2) {
+    store_tile(0, smem);
+    __syncthreads();
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * KT;
-    __syncthreads();            // previous tile fully consumed
-    store_tile(key0);
-    __syncthreads();
+    unsigned char* buf = smem + (NBUF == 2 ? (t & 1) * BUF_BYTES : 0);
+    if (NBUF == 1) {
+      __syncthreads();            // previous tile fully consumed
+      store_tile(key0, buf);
+      __syncthreads();
+    }
     if (t + 1 < ntiles) load_tile(key0 + KT);   // in flight during the MFMA / softmax block below
+    const unsigned char* ksm = buf;
+    const unsigned char* vsm = buf + K_BYTES;
 
-    // ---- S^T = K Q^T for two 32-key blocks ----
+    // LDS fragment readers.  K: row (kb*32 + r), slots 2s+h.  V^T: rows nb*32 + r, the 16 keys of step ks in the
+    // accumulator's k order (two 8-byte pieces at key offsets 4h and 8+4h).
+    auto read_k = [&](int kb, u32x4* kf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
+    };
+    auto read_v = [&](int ks, u32x4* vf) __attribute__((always_inline)) {
+      const int kofs = ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * h) * 2;  // bytes
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + kofs;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+        vf[nb] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+    };
+
+    // ---- S^T = K Q^T, one 32-key block per stage: the next block's K fragments (after the last block: the first
+    //      V^T fragments) are read and the previous block's row max is taken in the shadow of this block's MFMAs ----
     f32x16 acc_s[NKB];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr bool KPIPE = KS <= 4;          // wider heads keep one fragment set (register budget: occupancy 2)
+    u32x4 kf[KPIPE ? 2 : 1][KS];
+    u32x4 vcur[KPIPE ? NB : 1], vnxt[KPIPE ? NB : 1];
+    float mx = -INFINITY;
+    if (KPIPE) read_k(0, kf[0]);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+      if (KPIPE && kb + 1 < NKB) read_k(kb + 1, kf[(kb + 1) & 1]);
+      if (KPIPE && kb + 1 == NKB) read_v(0, vcur);
+      if (KPIPE && kb > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb - 1][i]);
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
-        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]),
+        // wide heads (!KPIPE): one fragment at a time, read where it is used (register budget)
+        const u32x4 kfrag = KPIPE ? kf[KPIPE ? (kb & 1) : 0][s]
+                                  : *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
+        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, qf[s]),
                                                             s == 0 ? zero16 : acc_s[kb], 0, 0, 0);   // C = inline 0
       }
+      if (KPIPE) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- masks only on the tiles that need them (wave-uniform) ----
+    // pin the partial row max here: without a use in this block the compiler sinks the in-stage max chain past the
+    // edge-tile branch below (it is dead on that path) and out of the MFMA shadows
+    if (KPIPE) asm volatile("" ::"v"(mx));
+    // ---- masks only on the tiles that need them (wave-uniform); the row max is then redone over the masked scores ----
     if (key0 + KT > p.nk || p.causal) {
+      mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (key >= p.nk || (p.causal && key > qi)) acc_s[kb][i] = -INFINITY;
+          if (KPIPE && kb + 1 < NKB) mx = fmaxf(mx, acc_s[kb][i]);
         }
     }
-    // ---- online softmax, query on the lane ----
-    float mx = acc_s[0][0];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = KPIPE ? NKB - 1 : 0; kb < NKB; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb][i]);
+    // ---- online softmax, query on the lane ----
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * c);
     if (__any(m_new > m_run)) {   // some query's max moved: rescale everything at the old max once
@@ -196,36 +245,54 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
     }
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][i], c, -m_run));
-        acc_s[kb][i] = pv;
-        if (!ONES) psum += pv;
-      }
-    if (!ONES) l_run += psum;
 
-    // ---- O^T += V^T P^T  (row D of V^T is ones when ONES: accumulates the denominator) ----
-#pragma unroll
-    for (int ks = 0; ks < 2 * NKB; ++ks) {
+    // ---- O^T += V^T P^T in 16-key steps (row D of V^T is ones when ONES: accumulates the denominator).  Software
+    //      pipeline: step ks+1's exp2 / bf16 pack and V^T fragment reads sit in the shadow of step ks's MFMAs ----
+    float psum = 0.f;
+    auto softmax_part = [&](int ks) __attribute__((always_inline)) -> u32x4 {
       const int kb = ks >> 1, half = ks & 1;
-      u32x4 pf;
-      pf.x = pack2(acc_s[kb][8 * half + 0], acc_s[kb][8 * half + 1]);
-      pf.y = pack2(acc_s[kb][8 * half + 2], acc_s[kb][8 * half + 3]);
-      pf.z = pack2(acc_s[kb][8 * half + 4], acc_s[kb][8 * half + 5]);
-      pf.w = pack2(acc_s[kb][8 * half + 6], acc_s[kb][8 * half + 7]);
-      const int koff = (kb * 32 + 16 * half + 4 * h) * 2;  // bytes
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][8 * half + j], c, -m_run));
+        if (!ONES) psum += e[j];
+      }
+      return u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+    };
+    u32x4 pf_cur = zero4, pf_nxt = zero4;
+    if (KPIPE) pf_cur = softmax_part(0);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      if (!KPIPE) {                       // wide heads: probabilities of this step only, fragments read at their MFMA
+        pf_cur = softmax_part(ks);
+      } else if (ks + 1 < NS) {
+        read_v(ks + 1, vnxt);
+        pf_nxt = softmax_part(ks + 1);
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + koff;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
-        const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
-        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                            __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+        u32x4 vf = vcur[KPIPE ? nb : 0];
+        if (!KPIPE) {
+          const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * h) * 2;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+          vf = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf_cur),
+                                                            acc_o[nb], 0, 0, 0);
       }
+      if (KPIPE) {
+        __builtin_amdgcn_sched_barrier(0);
+        pf_cur = pf_nxt;
+#pragma unroll
+        for (int nb = 0; nb < (KPIPE ? NB : 1); ++nb) vcur[nb] = vnxt[nb];
+      }
+    }
+    if (!ONES) l_run += psum;
+
+    if (NBUF == 2) {
+      if (t + 1 < ntiles) store_tile(key0 + KT, smem + ((t + 1) & 1) * BUF_BYTES);
+      __syncthreads();            // next tile visible; everyone is done with this one
     }
   }
 
@@ -259,6 +326,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   }
 }
 
+template <int KS, int NB, bool ONES, int KT>
+void launch_one(const SaspaAttnParams& p, hipStream_t s, dim3 grid) {
+  // two LDS tile buffers when two workgroups per CU still fit the 160 KiB (occupancy 2 is what overlaps one
+  // workgroup's softmax VALU with the other's MFMAs)
+  constexpr int buf_bytes = KT * ((2 * KS) | 1) * 16 + NB * 32 * (KT * 2 + 8);
+  constexpr int NBUF = (4 * buf_bytes <= 160 * 1024) ? 2 : 1;
+  hipLaunchKernelGGL((flash_attn_kernel<KS, NB, ONES, KT, NBUF>), grid, dim3(256), 0, s, p);
+}
+
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
@@ -267,11 +343,11 @@ int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   constexpr bool BIG_OK = KS <= 6;
   const bool big = BIG_OK && p.nk >= 512;
   if (p.D < 32 * NB) {
-    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64>), grid, dim3(256), 0, s, p);
+    if (big) launch_one<KS, NB, true, BIG_OK ? 128 : 64>(p, s, grid);
+    else launch_one<KS, NB, true, 64>(p, s, grid);
   } else {
-    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, 64>), grid, dim3(256), 0, s, p);
+    if (big) launch_one<KS, NB, false, BIG_OK ? 128 : 64>(p, s, grid);
+    else launch_one<KS, NB, false, 64>(p, s, grid);
   }
   SASPA_CHECK_LAUNCH();
   return 0;

@@ -78,12 +78,16 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const short* dxy, const 
   }
 }
 
-// one workgroup (1024 threads) per image; dynamic LDS = 2 * H * W32 words
-__global__ __launch_bounds__(1024) void canny_hysteresis_kernel(const uint8_t* map, uint8_t* dst, int H, int W) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t bits[];
+// one workgroup (1024 threads) per image; dynamic LDS = 2 * H * W32 words.  GLOBAL: images whose bitmaps exceed one CU's
+// LDS (e.g. 1024 x 1024) keep them in the caller's scratch instead -- same algorithm, same fixed point (the growth is
+// monotone, so the benign read/write overlap inside a sweep cannot change the result), L2-resident (256 KB per image).
+template <bool GLOBAL>
+__global__ __launch_bounds__(1024) void canny_hysteresis_kernel(const uint8_t* map, uint8_t* dst, int H, int W, uint32_t* gbits) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_bits[];
   __shared__ int changed;
   const int W32 = (W + 31) >> 5;
   const int nwords = H * W32;
+  uint32_t* bits = GLOBAL ? gbits + (long long)blockIdx.x * 2 * nwords : lds_bits;
   uint32_t* strong = bits;
   uint32_t* weak = bits + nwords;
   const uint8_t* mp = map + (long long)blockIdx.x * H * W;
@@ -155,7 +159,8 @@ extern "C" int saspa_canny(const uint8_t* src, uint8_t* dst, uint8_t* work, int 
   if (low > high) { const int t = low; low = high; high = t; }
   const int W32 = (W + 31) / 32;
   const size_t lds_bytes = (size_t)2 * H * W32 * 4;
-  if (lds_bytes > 160 * 1024 - 64) return SASPA_ERANGE;  // bitmaps must fit one CU's LDS
+  const bool in_lds = lds_bytes <= 160 * 1024 - 64;      // else the bitmaps live in the scratch tail (needs W >= 64)
+  if (!in_lds && W < 64) return SASPA_ERANGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long npix = (long long)n * H * W;
   // work layout: dxy int16[2*npix] | mag int16[npix] | map u8[npix]   (7 bytes / pixel)
@@ -168,14 +173,20 @@ extern "C" int saspa_canny(const uint8_t* src, uint8_t* dst, uint8_t* work, int 
   SASPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(canny_nms_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dxy, mag, map, n, H, W, low, high);
   SASPA_CHECK_LAUNCH();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(canny_hysteresis_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  if (in_lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(canny_hysteresis_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(canny_hysteresis_kernel<false>, dim3(n), dim3(1024), lds_bytes, s, map, dst, H, W, (uint32_t*)nullptr);
+  } else {
+    // scratch tail after the 7 bytes / pixel above: n * 2 * H * W32 words <= 0.4 bytes / pixel at W >= 64
+    uint32_t* gbits = reinterpret_cast<uint32_t*>(work + ((7 * npix + 15) & ~15ll));
+    hipLaunchKernelGGL(canny_hysteresis_kernel<true>, dim3(n), dim3(1024), 0, s, map, dst, H, W, gbits);
   }
-  hipLaunchKernelGGL(canny_hysteresis_kernel, dim3(n), dim3(1024), lds_bytes, s, map, dst, H, W);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

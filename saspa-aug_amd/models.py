@@ -610,7 +610,12 @@ class SafetyChecker:
         ps, w, heads = cfg["patch"], cfg["width"], cfg["heads"]
         g = pixels.shape[1] // ps
         pos = p["patch_pos"].view(1, g, g, w).expand(b, -1, -1, -1).contiguous()
-        tok = ops.conv(pixels, p[v + ".embeddings.patch_embedding.w"], None, kh=ps, kw=ps, stride=ps, pad=0, residual=pos)
+        # non-overlapping patches: view the image as B*g strips of ps rows whose "pixels" are whole patch rows
+        # (ps*8 channels), so the patch embedding is a ps x 1 window conv (ps taps) with the SAME packed weight
+        # (K index (ky*ps + kx)*8 + c either way) -- the 14 x 14 = 196-tap form exceeds the kernel's tap table
+        strips = pixels.contiguous().view(b * g, ps, g, ps * 8)
+        tok = ops.conv(strips, p[v + ".embeddings.patch_embedding.w"], None, kh=ps, kw=1, stride=1, pad=0,
+                       residual=pos.view(b * g, 1, g, w)).view(b, g, g, -1)
         x = torch.cat([p["cls_pos"].expand(b, -1, -1), tok.view(b, g * g, w)], 1).contiguous()
         n = x.shape[1]
         x = ops.layernorm(x, p[v + ".pre_layrnorm.g"], p[v + ".pre_layrnorm.b"])

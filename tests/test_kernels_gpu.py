@@ -334,12 +334,18 @@ def _synthetic_image(h, w, seed):
     return synthetic_image(h, w, seed)
 
 
-@pytest.mark.parametrize("h,w,seed", [(64, 64, 0), (96, 160, 1), (512, 512, 2), (37, 53, 3), (512, 704, 4)])
+@pytest.mark.parametrize("h,w,seed", [(64, 64, 0), (96, 160, 1), (512, 512, 2), (37, 53, 3), (512, 704, 4), (1024, 1024, 5),
+                                      (1024, 704, 6)])
 def test_canny_bit_exact(dev, h, w, seed):
+    """1024 x 1024 (BASELINE configs[4]) takes the path whose hysteresis bitmaps live in global scratch."""
     from oracle import canny as OC
     img = _synthetic_image(h, w, seed)
     ref = OC.generate_canny_array(img, 120, 200)
-    got = ops.canny(torch.from_numpy(img)[None].to(dev), 120, 200)[0].cpu().numpy()
+    batch = torch.from_numpy(np.stack([img, img[::-1].copy()])).to(dev) if h >= 1024 else torch.from_numpy(img)[None].to(dev)
+    got_all = ops.canny(batch, 120, 200).cpu().numpy()
+    got = got_all[0]
+    if h >= 1024:
+        assert np.array_equal(got_all[1], OC.generate_canny_array(img[::-1].copy(), 120, 200))
     assert ref.shape == got.shape
     assert np.array_equal(got, ref), f"{(got != ref).sum()} differing bytes; edge fraction {ref.mean() / 255:.3f}"
     assert 0.005 < ref.mean() / 255 < 0.5

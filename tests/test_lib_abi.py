@@ -47,7 +47,7 @@ def test_host_side_argument_validation_needs_no_gpu():
     q = _lib.AttnParams()
     assert lib.saspa_flash_attn_bf16(C.byref(q), None) == -1
     assert lib.saspa_canny(None, None, None, 1, 8, 8, 1, 2, None) == -1
-    assert lib.saspa_canny(base, base, (base + 15) // 16 * 16, 1, 4096, 4096, 1, 2, None) == -3   # bitmaps exceed LDS
+    assert lib.saspa_canny(base, base, (base + 15) // 16 * 16, 1, 100000, 32, 1, 2, None) == -3   # bitmaps exceed LDS and W < 64
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

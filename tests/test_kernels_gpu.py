@@ -348,7 +348,7 @@ def test_canny_bit_exact(dev, h, w, seed):
         assert np.array_equal(got_all[1], OC.generate_canny_array(img[::-1].copy(), 120, 200))
     assert ref.shape == got.shape
     assert np.array_equal(got, ref), f"{(got != ref).sum()} differing bytes; edge fraction {ref.mean() / 255:.3f}"
-    assert 0.005 < ref.mean() / 255 < 0.5
+    assert (0.002 if h >= 1024 else 0.005) < ref.mean() / 255 < 0.5
 
 
 def test_canny_noise_and_flat(dev):

@@ -49,6 +49,9 @@ extern "C" {
 #define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
 #define SASPA_GEMM_WIDE 2  /* 8-wave 256x320 / 256x256 tile, one workgroup per CU */
 
+#define SASPA_KORDER_TAP 0
+#define SASPA_KORDER_CHUNK 1
+
 /* ---- implicit-GEMM convolution / linear ----------------------------------
  * out[m][n] = act( alpha * (sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n]) ) + residual[m][n]
  * where m = (b, oy, ox) and A is the im2col view of up to two channel-concatenated
@@ -97,6 +100,12 @@ typedef struct SaspaGemmParams {
    * (long-K bf16 layers); it returns SASPA_ERANGE for a problem it cannot run (fp32, fused
    * GEGLU, channel counts that are not multiples of 64, windows other than 1x1 or 3x3/pad 1). */
   int variant;
+  /* K order of the packed weights (and of the K walk), ABI v4.  SASPA_KORDER_TAP: K = (ky*kw+kx)*C + c (tap-major, the
+   * default).  SASPA_KORDER_CHUNK: the C = c0+c1 channels are cut into chunks of one K-tile (64 bf16 / 32 fp32 elements)
+   * and K = ((chunk*kh*kw) + ky*kw+kx)*tile + c_in_chunk: the kh*kw taps of one channel chunk are consecutive K-tiles,
+   * so a workgroup re-reads the same input rows back to back (L2 hits) instead of once per pass over all channels.
+   * Requires c0 (and c1, if used) to be multiples of the K-tile; SASPA_ERANGE otherwise. */
+  int korder;
 } SaspaGemmParams;
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 

@@ -22,7 +22,7 @@ class GemmParams(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int), ("nb1", C.c_int), ("nb2", C.c_int),
         ("sa1", C.c_longlong), ("sa2", C.c_longlong), ("sw1", C.c_longlong), ("sw2", C.c_longlong),
         ("so1", C.c_longlong), ("so2", C.c_longlong), ("ksplit", C.c_int), ("workspace", C.c_void_p),
-        ("variant", C.c_int),
+        ("variant", C.c_int), ("korder", C.c_int),
     ]
 
 

@@ -611,10 +611,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       offb[i] = (n < p.N && r0 + RPI * i < BN) ? (unsigned)(n * p.ldw * SZ + kcs * 16) : kInvalid;
     }
     ku = kt0 * BK;
-    const int tapu = ku / ctot;
-    cu = ku - tapu * ctot;
-    dyu = tapu / p.kw;
-    dxu = tapu - dyu * p.kw;
+    if (p.korder == SASPA_KORDER_CHUNK) {
+      // chunk-major K: K-tile kt = (channel chunk kt / T, tap kt % T)
+      const int ntap = p.kh * p.kw;
+      const int chunk = kt0 / ntap, tap = kt0 - chunk * ntap;
+      cu = chunk * BK;
+      dyu = tap / p.kw;
+      dxu = tap - dyu * p.kw;
+    } else {
+      const int tapu = ku / ctot;
+      cu = ku - tapu * ctot;
+      dyu = tapu / p.kw;
+      dxu = tapu - dyu * p.kw;
+    }
   };
 
   auto dma_tile = [&](int stage) __attribute__((always_inline)) {
@@ -646,10 +655,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       if (RPI * (i + 1) <= BN || RPI * i + 8 * wave < BN)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (RPI * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
     ku += BK;
-    cu += BK;
-    if (cu >= ctot) {
-      cu -= ctot;
-      if (++dxu == p.kw) { dxu = 0; ++dyu; }
+    if (p.korder == SASPA_KORDER_CHUNK) {
+      if (++dxu == p.kw) {
+        dxu = 0;
+        if (++dyu == p.kh) { dyu = 0; cu += BK; }
+      }
+    } else {
+      cu += BK;
+      if (cu >= ctot) {
+        cu -= ctot;
+        if (++dxu == p.kw) { dxu = 0; ++dyu; }
+      }
     }
   };
 
@@ -797,6 +813,7 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   const int tiles_abl = tiles | (abl << 28);
   const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
                     (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
+  if (p.korder == SASPA_KORDER_CHUNK && !fast) return SASPA_ERANGE;   // only the DMA kernels walk K chunk-major
   if constexpr (NT != 256) {
     // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
     if (!fast) return SASPA_ERANGE;
@@ -915,6 +932,11 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     if (p.kh * p.kw > 31) return SASPA_ERANGE;
   }
   if (p.ksplit < 0 || p.ksplit > 64) return SASPA_ERANGE;
+  if (p.korder != SASPA_KORDER_TAP && p.korder != SASPA_KORDER_CHUNK) return SASPA_EINVAL;
+  if (p.korder == SASPA_KORDER_CHUNK) {
+    const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
+    if (p.c0 % bk || p.c1 % bk) return SASPA_ERANGE;
+  }
   if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_WIDE) return SASPA_EINVAL;
   if (p.act == SASPA_ACT_GEGLU) {
     // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)

@@ -163,10 +163,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     offb0 = (unsigned)((bn * BN + wave * 8 + lr) * p.ldw * SZ + kcs * 16);
     nrows = p.N - bn * BN;                             // N % 8 == 0: validity is uniform over an 8-row piece
     ku = kt0 * BK;
-    const int tapu = ku / ctot;
-    cu = ku - tapu * ctot;
-    dyu = tapu / p.kw;
-    dxu = tapu - dyu * p.kw;
+    if (p.korder == SASPA_KORDER_CHUNK) {
+      const int ntap = p.kh * p.kw;
+      const int chunk = kt0 / ntap, tap = kt0 - chunk * ntap;
+      cu = chunk * BK;
+      dyu = tap / p.kw;
+      dxu = tap - dyu * p.kw;
+    } else {
+      const int tapu = ku / ctot;
+      cu = ku - tapu * ctot;
+      dyu = tapu / p.kw;
+      dxu = tapu - dyu * p.kw;
+    }
     staged = 0;
     src = -1;
   };
@@ -214,10 +222,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     // advance to the following tile
     ++staged;
     ku += BK;
-    cu += BK;
-    if (cu >= ctot) {
-      cu -= ctot;
-      if (++dxu == p.kw) { dxu = 0; ++dyu; }
+    if (p.korder == SASPA_KORDER_CHUNK) {
+      if (++dxu == p.kw) {
+        dxu = 0;
+        if (++dyu == p.kh) { dyu = 0; cu += BK; }
+      }
+    } else {
+      cu += BK;
+      if (cu >= ctot) {
+        cu -= ctot;
+        if (++dxu == p.kw) { dxu = 0; ++dyu; }
+      }
     }
   };
   // LDS element (u32x4) index of the READ buffer (cur) and of the other one; swapped every K-tile

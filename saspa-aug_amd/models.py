@@ -43,12 +43,20 @@ class _Packed:
         w = self.sd[name + ".weight"]
         if w.dim() == 2:            # use_linear_projection (SDXL): a Linear over the token matrix == a 1x1 conv
             w = w[:, :, None, None]
+        kh, kw = w.shape[2], w.shape[3]
         if split is None:
             pk = W.pack_conv(w)
+            c0p, c1p = W.round8(w.shape[1]), 0
         else:
             c0, c1 = split
-            pk = W.pack_conv_split(w, c0, W.round8(c0), c1, W.round8(c1))
-        self.p[name + ".w"] = pk.to(self.dev, self.dtype)
+            c0p, c1p = W.round8(c0), W.round8(c1)
+            pk = W.pack_conv_split(w, c0, c0p, c1, c1p)
+        chunk = W.chunk_major_ok(kh, kw, c0p, c1p, self.dtype)
+        if chunk:       # the taps of one channel chunk become consecutive K-tiles (input rows re-read from L2)
+            pk = W.to_chunk_major(pk, kh * kw, self.dtype)
+        t = pk.to(self.dev, self.dtype)
+        t.saspa_korder = 1 if chunk else 0          # read by ops.conv -> SaspaGemmParams.korder
+        self.p[name + ".w"] = t
         if name + ".bias" in self.sd:
             self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
 

@@ -99,10 +99,11 @@ def _set_splitk(p, m, n, k, t):
 
 
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
-         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0):
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
-    (pad channels zero)."""
+    (pad channels zero).  ``korder``: K order the weights were packed in (default: the tensor's
+    ``saspa_korder`` attribute set by the packer, else tap-major)."""
     _check_dev(x, w, bias, x2, rowvec, residual, out)
     lib = _lib.load()
     b, h, wd, c0 = x.shape
@@ -133,6 +134,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.out, p.ldo = _ptr(out), _pitch4(out)
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
+    p.korder = int(getattr(w, "saspa_korder", 0)) if korder is None else int(korder)
     _ws = _set_splitk(p, p.M, p.N, p.K, x)  # noqa: F841
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
             (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))

@@ -306,6 +306,27 @@ def pack_conv_split(w, c0, c0_pad, c1, c1_pad):
     return torch.cat([a, b], -1).reshape(co, kh * kw * (c0_pad + c1_pad)).contiguous()
 
 
+def ktile(dtype):
+    """Elements of one K-tile of the implicit GEMM (128 bytes per row): 64 bf16 / 32 fp32."""
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def chunk_major_ok(kh, kw, c0_pad, c1_pad, dtype):
+    """A conv can be packed chunk-major (SASPA_KORDER_CHUNK) when it has a window and its (padded) source channel counts
+    are whole K-tiles -- exactly the layers the LDS-DMA kernels run."""
+    bk = ktile(dtype)
+    return kh * kw > 1 and c0_pad % bk == 0 and c1_pad % bk == 0
+
+
+def to_chunk_major(packed, taps, dtype):
+    """[N, taps*C] tap-major (K = tap*C + c) -> chunk-major (K = (chunk*taps + tap)*bk + c_in_chunk)."""
+    n, k = packed.shape
+    bk = ktile(dtype)
+    c = k // taps
+    assert c * taps == k and c % bk == 0
+    return packed.view(n, taps, c // bk, bk).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+
+
 def pack_linear(w, k_pad=None):
     n, k = w.shape
     kp = round8(k) if k_pad is None else k_pad

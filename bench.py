@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-safety-checker", action="store_true",
+                    help="A/B only: the reference never disables the SD-1.5 safety checker, so the default step runs it")
     ap.add_argument("--tiny", action="store_true", help="reduced-width family (plumbing check only; INVALID as a result)")
     args = ap.parse_args()
 
@@ -138,6 +140,8 @@ def main():
 
     cfgs = CFG.tiny() if args.tiny else CFG.SD15
     pipe = StableDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0).to(dev, torch.bfloat16)
+    if args.no_safety_checker:
+        pipe.safety_checker = None
     b, res, s = args.batch, args.res, args.ddim_steps
     vocab = cfgs["text"]["vocab"]
     neg = negative_prompt_ids(vocab)

@@ -314,6 +314,9 @@ def ktile(dtype):
 def chunk_major_ok(kh, kw, c0_pad, c1_pad, dtype):
     """A conv can be packed chunk-major (SASPA_KORDER_CHUNK) when it has a window and its (padded) source channel counts
     are whole K-tiles -- exactly the layers the LDS-DMA kernels run."""
+    import os
+    if os.environ.get("SASPA_KORDER", "1") == "0":          # A/B knob: keep every conv tap-major
+        return False
     bk = ktile(dtype)
     return kh * kw > 1 and c0_pad % bk == 0 and c1_pad % bk == 0
 

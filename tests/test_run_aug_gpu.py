@@ -10,7 +10,8 @@ import saspa_aug_amd  # noqa: F401
 from saspa_aug_amd import config as CFG
 from saspa_aug_amd import run_aug as R
 from saspa_aug_amd import weights as W
-from saspa_aug_amd.pipeline import BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline
+from saspa_aug_amd.pipeline import (BlipDiffusionControlNetPipeline, StableDiffusionControlNetPipeline,
+                                    StableDiffusionXLControlNetPipeline)
 
 pytestmark = pytest.mark.gpu
 
@@ -48,3 +49,20 @@ def test_run_aug_end_to_end(dev, tmp_path, base_model):
     # a second run finds every output on disk and generates nothing
     res2 = R.main(s, pipe=pipe)
     assert all(it.skip for it in res2["items"]) and (res2["status"] == 0).all()
+
+
+def test_run_aug_end_to_end_sdxl_turbo(dev, tmp_path):
+    """The sd_xl-turbo settings of the reference (run_aug/run_aug.py:567-571: guidance 0, 2 steps, no negative prompt)
+    through the same loop: output tree under controlnet/sd_xl-turbo/canny, JSON contract unchanged."""
+    cfgs = CFG.tiny_xl()
+    fam = W.synth_family(cfgs, seed=3)
+    pipe = R.init_pipeline("sd_xl-turbo", "canny", 0, cfgs=cfgs, state_dicts=fam).to("cuda:0", torch.float16)
+    assert isinstance(pipe, StableDiffusionXLControlNetPipeline) and pipe.vae.dtype == torch.float32
+    s = _settings(tmp_path, "sd_xl-turbo", GUIDANCE_SCALE=0)
+    s.NUM_INFERENCE_STEPS = 2
+    res = R.main(s, pipe=pipe)
+    out = Path(res["output_folder"])
+    assert "aug_data/controlnet/sd_xl-turbo/canny/" in str(out)
+    assert (res["status"] == 1).all() and len(res["items"]) == 10
+    body = json.load(open(res["json_path"]))
+    assert len(body) == 5 and all(len(v) == 2 for v in body.values())

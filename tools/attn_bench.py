@@ -7,6 +7,9 @@ from saspa_aug_amd import ops
 dev = torch.device('cuda:0')
 shapes = [(16, 8, 4096, 4096, 40), (16, 8, 1024, 1024, 80), (16, 8, 256, 256, 160), (16, 8, 4096, 77, 40), (16, 8, 1024, 77, 80),
           (8, 10, 1024, 1024, 64), (8, 20, 256, 256, 64), (8, 10, 4096, 4096, 64), (8, 10, 1024, 77, 64)]
+if len(sys.argv) > 1 and sys.argv[1] == "quick":
+    shapes = [shapes[0], shapes[7], shapes[5]]
+print("SASPA_ATTN_MODE =", os.environ.get("SASPA_ATTN_MODE"), flush=True)
 for (B, H, NQ, NK, D) in shapes:
     C = H * D
     q = torch.randn(B, NQ, C, device=dev).bfloat16()

@@ -15,15 +15,12 @@
 // LDS images: K tile rows padded to an odd number of 16-byte slots (conflict-free
 // ds_read_b128 across 32 distinct rows); V^T rows = 64 keys + 8 bytes pad (conflict-free
 // ds_read_b64: row stride 136 B = 8*17).
-#include <cstdlib>
-
 #include "common.h"
 
 namespace {
 
-// ---- round-1 baseline loop (single LDS tile, fragments read at their MFMA): kept as the A/B reference, SASPA_ATTN_MODE=0 ----
 template <int KS, int NB, bool ONES, int KT>
-__global__ __launch_bounds__(256) void flash_attn_kernel_v0(const SaspaAttnParams p) {
+__global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
   // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key
   constexpr int NKB = KT / 32;               // 32-key blocks of S^T per tile
   constexpr int VCH = KT / 8;                // 16-byte chunks per V^T row
@@ -45,9 +42,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel_v0(const SaspaAttnParam
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+  // plain (query block fastest) order puts every (batch, head)'s K / V^T into all 8 L2s -- 8x the HBM-side fetch (PMC:
+  // 713 MB per level-0 launch against 168 MB of operands).  Remap: ids congruent mod 8 (= one XCD) walk the query blocks
+  // of ONE (batch, head); the 8 pairs of a group share the 8 XCDs.  A tail group of fewer than 8 pairs is spread evenly.
+  const int gx = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int grp = lin / (8 * gx), rr = lin - grp * 8 * gx;
+  const int gsz = min(8, nbh - grp * 8);
+  const int bh = grp * 8 + rr % gsz, xq = rr / gsz;
+  const int head = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
   const int D = p.D, D8 = D >> 3;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = xq * 128 + wave * 32;
   const int qi = q0 + r;  // this lane's query
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
@@ -262,347 +268,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel_v0(const SaspaAttnParam
   }
 }
 
-
-template <int KS, int NB, bool ONES, int KT, int NBUF, int MODE>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const SaspaAttnParams p) {
-  // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key.
-  // NBUF = LDS tile buffers.  2: the next tile is written into the other buffer at the END of an iteration, so one
-  // barrier per tile and the LDS stores are off the barrier-to-barrier path; 1: store between two barriers.
-  constexpr int NKB = KT / 32;               // 32-key blocks of S^T per tile
-  constexpr int NS = 2 * NKB;                // 16-key PV steps per tile
-  constexpr int VCH = KT / 8;                // 16-byte chunks per V^T row
-  // ONES: D < 32*NB, so V^T row D is a spare MFMA row; it is filled with ones and the PV
-  // MFMA then accumulates the softmax denominator there (no VALU row-sum in the loop).
-  constexpr int KSLOTS = (2 * KS) | 1;       // 16-byte slots per K row (odd)
-  constexpr int KCH = 2 * KS;                // chunks per K row that are written
-  constexpr int DV = NB * 32;
-  constexpr int VROW = KT * 2 + 8;           // bytes; (VROW/8) odd -> conflict-free ds_read_b64
-  constexpr int K_BYTES = KT * KSLOTS * 16;
-  constexpr int V_BYTES = DV * VROW;
-  constexpr int BUF_BYTES = K_BYTES + V_BYTES;
-  constexpr int NCH_K = (KT * KCH + 255) / 256;
-  constexpr int NCH_V = (DV * VCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUF_BYTES];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int D = p.D, D8 = D >> 3;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  const int qi = q0 + r;  // this lane's query
-
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
-  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
-  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
-  bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
-
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  // ---- Q fragments (B operand), resident for the whole kernel ----
-  u32x4 qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int d = 16 * s + 8 * h;
-    qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
-  }
-
-  // ---- staging: bounds-checked buffer loads (an offset >= num_records returns zeros), per-lane
-  //      offsets fixed for the whole kernel, the tile advance in a scalar offset ----
-  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kp), (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
-  constexpr unsigned kInv = 0x80000000u;
-  unsigned koff[NCH_K], voff[NCH_V];
-  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_kc[NCH_V];
-#pragma unroll
-  for (int i = 0; i < NCH_K; ++i) {
-    const int q = tid + 256 * i;
-    const int key = q / KCH, ch = q - key * KCH;
-    k_key[i] = key;
-    k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
-    koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;   // pad chunks read as zeros
-  }
-#pragma unroll
-  for (int i = 0; i < NCH_V; ++i) {
-    const int q = tid + 256 * i;
-    const int d = q / VCH, kc = q - d * VCH;
-    v_kc[i] = kc;
-    v_lds[i] = (q < DV * VCH && d < D) ? K_BYTES + d * VROW + kc * 16 : -1;     // rows >= D are written once, below
-    voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
-  }
-  // rows D .. DV-1 of the V^T tile never change: ones (denominator row, when ONES) / zeros
-  for (int q = tid; q < DV * VCH; q += 256) {
-    const int d = q / VCH, kc = q - d * VCH;
-    if (d >= D) {
-      const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
-#pragma unroll
-      for (int bi = 0; bi < NBUF; ++bi) {
-        u32x2* dst = reinterpret_cast<u32x2*>(smem + bi * BUF_BYTES + K_BYTES + d * VROW + kc * 16);
-        dst[0] = u32x2{fill, fill};
-        dst[1] = u32x2{fill, fill};
-      }
-    }
-  }
-  u32x4 kreg[NCH_K], vreg[NCH_V];
-
-  auto load_tile = [&](int key0) __attribute__((always_inline)) {
-    const bool tail = key0 + KT > p.nk;                  // wave-uniform
-    const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
-#pragma unroll
-    for (int i = 0; i < NCH_K; ++i) {
-      unsigned o = koff[i];
-      if (tail && key0 + k_key[i] >= p.nk) o = kInv;
-      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)o, (int)sk, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_V; ++i) {
-      unsigned o = voff[i];
-      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
-    }
-  };
-  auto store_tile = [&](int key0, unsigned char* buf) __attribute__((always_inline)) {
-    const bool tail = key0 + KT > p.nk;   // wave-uniform: only the last tile can hold keys >= nk
-#pragma unroll
-    for (int i = 0; i < NCH_K; ++i)
-      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(buf + k_lds[i]) = kreg[i];
-#pragma unroll
-    for (int i = 0; i < NCH_V; ++i) {
-      if (v_lds[i] >= 0) {
-        u32x4 v = vreg[i];
-        if (tail) {
-          // zero the keys >= nk (pad columns of vt are not initialised by the producer)
-          const int nvalid = p.nk - (key0 + v_kc[i] * 8);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
-            v[e] &= keep;
-          }
-        }
-        u32x2* dst = reinterpret_cast<u32x2*>(buf + v_lds[i]);
-        dst[0] = u32x2{v.x, v.y};
-        dst[1] = u32x2{v.z, v.w};
-      }
-    }
-  };
-
-  f32x16 acc_o[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
-  const float c = p.scale * 1.4426950408889634f;   // scores are kept raw; exp2(s*c - m) folds the scale
-  float m_run = -1e30f;                             // running max, already multiplied by c
-  float l_run = 0.f;                                // VALU row-sum (only when !ONES)
-
-  const int ntiles = (p.nk + KT - 1) / KT;
-  load_tile(0);
-  if (NBUF == 2) {
-    store_tile(0, smem);
-    __syncthreads();
-  }
-  for (int t = 0; t < ntiles; ++t) {
-    const int key0 = t * KT;
-    unsigned char* buf = smem + (NBUF == 2 ? (t & 1) * BUF_BYTES : 0);
-    if (NBUF == 1) {
-      __syncthreads();            // previous tile fully consumed
-      store_tile(key0, buf);
-      __syncthreads();
-    }
-    if (t + 1 < ntiles) load_tile(key0 + KT);   // in flight during the MFMA / softmax block below
-    const unsigned char* ksm = buf;
-    const unsigned char* vsm = buf + K_BYTES;
-
-    // LDS fragment readers.  K: row (kb*32 + r), slots 2s+h.  V^T: rows nb*32 + r, the 16 keys of step ks in the
-    // accumulator's k order (two 8-byte pieces at key offsets 4h and 8+4h).
-    auto read_k = [&](int kb, u32x4* kf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
-    };
-    auto read_v = [&](int ks, u32x4* vf) __attribute__((always_inline)) {
-      const int kofs = ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * h) * 2;  // bytes
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + kofs;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
-        vf[nb] = u32x4{lo.x, lo.y, hi.x, hi.y};
-      }
-    };
-
-    // ---- S^T = K Q^T, one 32-key block per stage: the next block's K fragments (after the last block: the first
-    //      V^T fragments) are read and the previous block's row max is taken in the shadow of this block's MFMAs ----
-    f32x16 acc_s[NKB];
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // MODE bits (tuning; launch_one picks the measured best): 1 = fragment / probability software pipeline (narrow heads
-    // only: wider heads keep one fragment set for the register budget of occupancy 2), 2 = sched_barrier stage fences,
-    // 4 = row max of block kb-1 in the MFMA shadow of block kb
-    constexpr bool KPIPE = (MODE & 1) && KS <= 4;
-    constexpr bool FENCE = (MODE & 2) != 0;
-    constexpr bool MAXSH = (MODE & 4) != 0;
-    u32x4 kf[KPIPE ? 2 : 1][KS];
-    u32x4 vcur[KPIPE ? NB : 1], vnxt[KPIPE ? NB : 1];
-    float mx = -INFINITY;
-    if (KPIPE) read_k(0, kf[0]);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (KPIPE && kb + 1 < NKB) read_k(kb + 1, kf[(kb + 1) & 1]);
-      if (KPIPE && kb + 1 == NKB) read_v(0, vcur);
-      if (MAXSH && kb > 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb - 1][i]);
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        // wide heads (!KPIPE): one fragment at a time, read where it is used (register budget)
-        const u32x4 kfrag = KPIPE ? kf[KPIPE ? (kb & 1) : 0][s]
-                                  : *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
-        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, qf[s]),
-                                                            s == 0 ? zero16 : acc_s[kb], 0, 0, 0);   // C = inline 0
-      }
-      if (FENCE) __builtin_amdgcn_sched_barrier(0);
-    }
-    // pin the partial row max here: without a use in this block the compiler sinks the in-stage max chain past the
-    // edge-tile branch below (it is dead on that path) and out of the MFMA shadows
-    if (MAXSH) asm volatile("" ::"v"(mx));
-    // ---- masks only on the tiles that need them (wave-uniform); the row max is then redone over the masked scores ----
-    if (key0 + KT > p.nk || p.causal) {
-      mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (key >= p.nk || (p.causal && key > qi)) acc_s[kb][i] = -INFINITY;
-          if (MAXSH && kb + 1 < NKB) mx = fmaxf(mx, acc_s[kb][i]);
-        }
-    }
-#pragma unroll
-    for (int kb = MAXSH ? NKB - 1 : 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb][i]);
-    // ---- online softmax, query on the lane ----
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    if (__any(m_new > m_run)) {   // some query's max moved: rescale everything at the old max once
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      if (!ONES) l_run *= alpha;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
-    }
-
-    // ---- O^T += V^T P^T in 16-key steps (row D of V^T is ones when ONES: accumulates the denominator).  Software
-    //      pipeline: step ks+1's exp2 / bf16 pack and V^T fragment reads sit in the shadow of step ks's MFMAs ----
-    float psum = 0.f;
-    auto softmax_part = [&](int ks) __attribute__((always_inline)) -> u32x4 {
-      const int kb = ks >> 1, half = ks & 1;
-      float e[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][8 * half + j], c, -m_run));
-        if (!ONES) psum += e[j];
-      }
-      return u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
-    };
-    u32x4 pf_cur = zero4, pf_nxt = zero4;
-    if (KPIPE) pf_cur = softmax_part(0);
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      if (!KPIPE) {                       // wide heads: probabilities of this step only, fragments read at their MFMA
-        pf_cur = softmax_part(ks);
-      } else if (ks + 1 < NS) {
-        read_v(ks + 1, vnxt);
-        pf_nxt = softmax_part(ks + 1);
-      }
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        u32x4 vf = vcur[KPIPE ? nb : 0];
-        if (!KPIPE) {
-          const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * h) * 2;
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
-          const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
-          vf = u32x4{lo.x, lo.y, hi.x, hi.y};
-        }
-        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf_cur),
-                                                            acc_o[nb], 0, 0, 0);
-      }
-      if (KPIPE) {
-        if (FENCE) __builtin_amdgcn_sched_barrier(0);
-        pf_cur = pf_nxt;
-#pragma unroll
-        for (int nb = 0; nb < (KPIPE ? NB : 1); ++nb) vcur[nb] = vnxt[nb];
-      }
-    }
-    if (!ONES) l_run += psum;
-
-    if (NBUF == 2) {
-      if (t + 1 < ntiles) store_tile(key0 + KT, smem + ((t + 1) & 1) * BUF_BYTES);
-      __syncthreads();            // next tile visible; everyone is done with this one
-    }
-  }
-
-  // ---- normalise and store: lane holds O[qi][d], d = 32*nb + 8*g + 4*h + (0..3) ----
-  float l_tot;
-  if (ONES) {
-    // the denominator sits in accumulator row D: block D/32, register 4*((D%32)/8), half h = 0
-    float lsel = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        if (32 * nb + 8 * g == D) lsel = acc_o[nb][4 * g];
-    l_tot = __shfl(lsel, r, 64);
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  }
-  const float inv = 1.0f / l_tot;
-  if (qi < p.nq) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * nb + 8 * g + 4 * h;
-        if (d < D) {
-          float v[4] = {acc_o[nb][4 * g + 0] * inv, acc_o[nb][4 * g + 1] * inv, acc_o[nb][4 * g + 2] * inv,
-                        acc_o[nb][4 * g + 3] * inv};
-          Elem<bf16_t>::store4(O + (long long)qi * p.ldo + d, v);
-        }
-      }
-  }
-}
-
-template <int KS, int NB, bool ONES, int KT>
-void launch_one(const SaspaAttnParams& p, hipStream_t s, dim3 grid) {
-  // two LDS tile buffers when two workgroups per CU still fit the 160 KiB (occupancy 2 is what overlaps one
-  // workgroup's softmax VALU with the other's MFMAs)
-  constexpr int buf_bytes = KT * ((2 * KS) | 1) * 16 + NB * 32 * (KT * 2 + 8);
-  constexpr int NBUF = (4 * buf_bytes <= 160 * 1024) ? 2 : 1;
-  // SASPA_ATTN_MODE = 10 * nbuf + mode (tuning knob, head dims 40 / 64 only): e.g. 10 = the single-buffer plain loop
-  static const int knob = getenv("SASPA_ATTN_MODE") ? atoi(getenv("SASPA_ATTN_MODE")) : -1;
-  if (knob == 0) {
-    hipLaunchKernelGGL((flash_attn_kernel_v0<KS, NB, ONES, KT>), grid, dim3(256), 0, s, p);
-    return;
-  }
-  if constexpr (KS == 3 || KS == 4) {
-    if (knob >= 0) {
-      const int nb = knob / 10, mode = knob % 10;
-#define SASPA_ATTN_CASE(NBF, MD)                                                                              \
-  if (nb == NBF && mode == MD) {                                                                             \
-    hipLaunchKernelGGL((flash_attn_kernel<KS, NB, ONES, KT, (NBF == 2 ? NBUF : 1), MD>), grid, dim3(256), 0, s, p); \
-    return;                                                                                                  \
-  }
-      SASPA_ATTN_CASE(1, 0) SASPA_ATTN_CASE(2, 0) SASPA_ATTN_CASE(1, 1) SASPA_ATTN_CASE(2, 1) SASPA_ATTN_CASE(2, 3)
-      SASPA_ATTN_CASE(2, 4) SASPA_ATTN_CASE(2, 5) SASPA_ATTN_CASE(2, 7) SASPA_ATTN_CASE(1, 7) SASPA_ATTN_CASE(1, 4)
-#undef SASPA_ATTN_CASE
-    }
-  }
-  hipLaunchKernelGGL((flash_attn_kernel<KS, NB, ONES, KT, NBUF, 7>), grid, dim3(256), 0, s, p);
-}
-
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
@@ -611,11 +276,11 @@ int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
   constexpr bool BIG_OK = KS <= 6;
   const bool big = BIG_OK && p.nk >= 512;
   if (p.D < 32 * NB) {
-    if (big) launch_one<KS, NB, true, BIG_OK ? 128 : 64>(p, s, grid);
-    else launch_one<KS, NB, true, 64>(p, s, grid);
+    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64>), grid, dim3(256), 0, s, p);
   } else {
-    if (big) launch_one<KS, NB, false, BIG_OK ? 128 : 64>(p, s, grid);
-    else launch_one<KS, NB, false, 64>(p, s, grid);
+    if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, 64>), grid, dim3(256), 0, s, p);
   }
   SASPA_CHECK_LAUNCH();
   return 0;

@@ -35,6 +35,12 @@
 #include "common.h"
 #include "gemm_internal.h"
 
+#ifdef SASPA_NO_KORDER
+constexpr bool KORDER_ON = false;   // A/B build: the K walk exactly as before ABI v4
+#else
+constexpr bool KORDER_ON = true;
+#endif
+
 namespace {
 
 typedef bf16_t T;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 
   const int hw = p.hout * p.wout;
   const int ctot = p.c0 + p.c1;
+  const int chunk_major = (KORDER_ON && p.korder == SASPA_KORDER_CHUNK) ? 1 : 0;   // wave-uniform
   const int hv = UP ? 2 * p.hin : p.hin, wv = UP ? 2 * p.win : p.win;
   // A descriptors: for the 3x3 / pad 1 window the base is moved back by one row + one pixel so that the
   // tap offset (dy*win + dx) * pitch is a non-negative SCALAR offset (no per-lane arithmetic per tap)
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     offb0 = (unsigned)((bn * BN + wave * 8 + lr) * p.ldw * SZ + kcs * 16);
     nrows = p.N - bn * BN;                             // N % 8 == 0: validity is uniform over an 8-row piece
     ku = kt0 * BK;
-    if (p.korder == SASPA_KORDER_CHUNK) {
+    if (chunk_major) {
       const int ntap = p.kh * p.kw;
       const int chunk = kt0 / ntap, tap = kt0 - chunk * ntap;
       cu = chunk * BK;
@@ -222,11 +229,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     // advance to the following tile
     ++staged;
     ku += BK;
-    if (p.korder == SASPA_KORDER_CHUNK) {
-      if (++dxu == p.kw) {
-        dxu = 0;
-        if (++dyu == p.kh) { dyu = 0; cu += BK; }
-      }
+    if (KORDER_ON) {
+      // branch-free mixed-radix step (a scalar branch in this path costs the DMA kernels ~25 %, measured): tap-major
+      // counts (c, x, y) with the channel offset fastest, chunk-major (x, y, c) with the tap fastest
+      const int cu_t = cu + BK;
+      const int wc = (cu_t >= ctot) ? 1 : 0;                        // tap-major: channel wrap carries into x
+      const int dx1 = dxu + (chunk_major ? 1 : wc);
+      const int wx = (dx1 == p.kw) ? 1 : 0;
+      const int dy1 = dyu + wx;
+      const int wy = (chunk_major && dy1 == p.kh) ? 1 : 0;          // chunk-major: tap wrap carries into the chunk
+      cu = chunk_major ? cu + (wy ? BK : 0) : (wc ? cu_t - ctot : cu_t);
+      dxu = wx ? 0 : dx1;
+      dyu = wy ? 0 : dy1;
     } else {
       cu += BK;
       if (cu >= ctot) {

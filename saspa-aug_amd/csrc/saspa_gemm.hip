@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
     }
   };
 
-  auto dma_tile = [&](int stage, bool live = true) __attribute__((always_inline)) {
+  auto dma_tile = [&](int stage) __attribute__((always_inline)) {
     if (abl & 4) return;
     const bool s0 = cu < p.c0;
     const rsrc_t rs = s0 ? rs0 : rs1;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
         px = pix[i] + iy * p.win + ix;
       }
       const unsigned off = (unsigned)(px * ldsz + kcs * 16);
-      const bool ok = live && (PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0));
+      const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
       if (BM % RPI == 0 || RPI * i + 8 * wave < BM)   // compile-time true for whole groups: no branch around the DMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (RPI * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
                                                  soff, 0, 0);
@@ -660,8 +660,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       if (RPI * (i + 1) <= BN || RPI * i + 8 * wave < BN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (RPI * i + 8 * wave) * 8), 16,
-                                                 (int)(live ? offb[i] : kInvalid), soffw, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (RPI * i + 8 * wave) * 8), 16, (int)offb[i], soffw, 0, 0);
     ku += BK;
     if (KORDER_ON) {
       // branch-free mixed-radix step (a scalar branch in this path costs the DMA kernels ~25 %, measured): tap-major
@@ -750,13 +749,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       }
       __builtin_amdgcn_s_barrier();                    // everyone's share landed; stage of tile kt-1 is free
       asm volatile("" ::: "memory");
-#ifdef SASPA_DMA_TAILFREE
-      // experiment: no branch around the DMA issue -- past the last K-tile the pieces are issued with out-of-range
-      // offsets (zero fill into the free stage, no memory traffic)
-      dma_tile((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1 < nk);
-#else
+      // (issuing the tail's pieces unconditionally with out-of-range offsets instead of this branch: measured 1.2 % slower)
       if (kt + NSTAGE - 1 < nk) dma_tile((kt + NSTAGE - 1) % NSTAGE);
-#endif
       // the DMA must be ISSUED before the MFMA block so that it flies under it: without this fence
       // hipcc's scheduler sinks all but one buffer_load..lds below the MFMAs (measured: DMA time
       // and compute time then add up instead of overlapping)

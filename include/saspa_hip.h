@@ -230,6 +230,17 @@ int saspa_resample_u8(const uint8_t* src, uint8_t* dst, long long outer, int in_
 int saspa_u8_to_act_norm(int dtype, const uint8_t* src, void* dst, long long npix, float mean0, float mean1, float mean2,
                          float std0, float std1, float std2, void* stream);
 
+/* StableDiffusionSafetyChecker decision + black-out on the device (no host round trip; SURVEY 8a: a7.9):
+ * dots [nimg][ldd] = image embedding . unit(special-care | concept embeddings) (special-care columns first),
+ * gram [nimg][ldg] = e e^T (diagonal = |e|^2), both fp32 GEMM outputs; special_w / concept_w = the fp64 thresholds.
+ * Per image, in fp64 and upstream's order: cos = dot/|e|; a special-care score cos - w >= threshold sets the 0.01
+ * adjustment; the image is flagged when any concept score cos - w + adjustment >= threshold, where `threshold` is
+ * the smallest double t with Python's round(t, 3) > 0 (the host computes it once).  flags[i] = 0/1; the bytes of a
+ * flagged image (bytes_per_image, multiple of 16) are zeroed -- upstream's black image. */
+int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, int nimg, const double* special_w,
+                        int n_special, const double* concept_w, int n_concepts, double threshold, uint8_t* images,
+                        long long bytes_per_image, int* flags, void* stream);
+
 /* library self-description */
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);

@@ -134,9 +134,11 @@ def safety_checker_forward(sd, cfg, clip_input):
     flags, cs, ss = [], [], []
     for i in range(emb.shape[0]):
         adj = 0.0
-        s_scores = [round(float(special[i, j] - sw[j] + adj), 3) for j in range(len(sw))]
-        if any(v > 0 for v in s_scores):
-            adj = 0.01
+        s_scores = []
+        for j in range(len(sw)):                      # upstream: the adjustment switches on INSIDE this loop
+            s_scores.append(round(float(special[i, j] - sw[j] + adj), 3))
+            if s_scores[-1] > 0:
+                adj = 0.01
         c_scores = [round(float(concept[i, j] - cw[j] + adj), 3) for j in range(len(cw))]
         flags.append(any(v > 0 for v in c_scores))
         cs.append(c_scores)

@@ -54,6 +54,39 @@ __global__ __launch_bounds__(256) void u8_to_act_norm_kernel(const uint8_t* src,
   }
 }
 
+// StableDiffusionSafetyChecker's per-image decision + black-out without a host round trip: grid (slices, images); every
+// block re-derives its image's flag from the 20 similarities (fp64, the same operation order as upstream's Python:
+// cos = dot / |e|, score = cos - weight + adjustment, "round(score, 3) > 0" as the equivalent threshold compare).
+__global__ __launch_bounds__(256) void safety_decide_kernel(const float* __restrict__ dots, int ldd, const float* __restrict__ gram,
+                                                            int ldg, const double* __restrict__ special_w, int ns,
+                                                            const double* __restrict__ concept_w, int nc, double thr,
+                                                            uint8_t* images, long long bytes_per_image, int* flags) {
+  __shared__ int flagged;
+  const int img = blockIdx.y;
+  if (threadIdx.x == 0) {
+    const double norm = sqrt((double)gram[(long long)img * ldg + img]);
+    double adj = 0.0;
+    for (int j = 0; j < ns; ++j) {
+      const double sc = (double)dots[(long long)img * ldd + j] / norm - special_w[j] + adj;
+      if (sc >= thr) { adj = 0.01; break; }         // upstream: adjustment once ANY special-care score is positive
+    }
+    int f = 0;
+    for (int j = 0; j < nc; ++j) {
+      const double sc = (double)dots[(long long)img * ldd + ns + j] / norm - concept_w[j] + adj;
+      if (sc >= thr) f = 1;
+    }
+    flagged = f;
+    if (blockIdx.x == 0) flags[img] = f;
+  }
+  __syncthreads();
+  if (!flagged) return;
+  uint8_t* base = images + (long long)img * bytes_per_image;
+  // 16-byte stores over the image's slice of this block (bytes_per_image % 16 == 0 is checked by the launcher)
+  const long long n16 = bytes_per_image / 16;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < n16; it += (long long)gridDim.x * 256)
+    reinterpret_cast<uint4*>(base)[it] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 unsigned grid_for(long long items) {
   long long g = (items + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -85,6 +118,21 @@ extern "C" int saspa_u8_to_act_norm(int dtype, const uint8_t* src, void* dst, lo
     hipLaunchKernelGGL(u8_to_act_norm_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, s, src, (float*)dst, npix, mean0, mean1, mean2, std0, std1, std2);
   else
     return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, int nimg, const double* special_w,
+                                   int n_special, const double* concept_w, int n_concepts, double threshold, uint8_t* images,
+                                   long long bytes_per_image, int* flags, void* stream) {
+  if (!dots || !gram || !special_w || !concept_w || !images || !flags || nimg <= 0 || n_special < 0 || n_concepts <= 0)
+    return SASPA_EINVAL;
+  if (ldd < n_special + n_concepts || ldg < nimg) return SASPA_ERANGE;
+  if (bytes_per_image <= 0 || bytes_per_image % 16 || !aligned16(images)) return SASPA_EALIGN;
+  const unsigned slices = (unsigned)((bytes_per_image / 16 + 256 * 16 - 1) / (256 * 16));
+  hipLaunchKernelGGL(safety_decide_kernel, dim3(slices < 1 ? 1 : (slices > 256 ? 256 : slices), nimg), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dots, ldd, gram, ldg, special_w, n_special, concept_w, n_concepts,
+                     threshold, images, bytes_per_image, flags);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

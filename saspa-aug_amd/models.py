@@ -608,6 +608,14 @@ class SafetyChecker:
         p["embeds_n"] = torch.nn.functional.normalize(emb.float()).contiguous().to(dev)        # constant: unit rows
         self.special_w = sd["special_care_embeds_weights"].double().numpy()
         self.concept_w = sd["concept_embeds_weights"].double().numpy()
+        p["special_w"] = sd["special_care_embeds_weights"].double().contiguous().to(dev)
+        p["concept_w"] = sd["concept_embeds_weights"].double().contiguous().to(dev)
+        # upstream decides on `round(score, 3) > 0`; round() is monotone, so that is `score >= t` for the smallest
+        # double t that rounds to a positive value -- found once by walking down from 0.0005
+        t = 0.0005
+        while round(t, 3) > 0:
+            t = math.nextafter(t, 0.0)
+        self.round_threshold = math.nextafter(t, 1.0)
         pk.sd = None
 
     def image_embeds(self, pixels):
@@ -649,8 +657,9 @@ class SafetyChecker:
         return ops.linear(e, self.p["embeds_n"]), ops.linear(e, e)
 
     def decide(self, dots, gram):
-        """Upstream's per-image thresholding, on the host (20 numbers per image): cos = dots / |e|, scores rounded to 3
-        decimals, +0.01 once a special-care concept fires -> (flags, concept scores, special scores)."""
+        """Upstream's per-image thresholding on the HOST (diagnostics / tests; `forward` takes the same decision on the
+        device): cos = dots / |e|, scores rounded to 3 decimals, +0.01 once a special-care concept fires ->
+        (flags, concept scores, special scores)."""
         dots = dots.double().cpu().numpy()
         norm = np.sqrt(np.diagonal(gram.double().cpu().numpy()[:, :dots.shape[0]]))
         ns, ncp = len(self.special_w), len(self.concept_w)
@@ -658,9 +667,11 @@ class SafetyChecker:
         flags, cs, ss = [], [], []
         for i in range(cos.shape[0]):
             adj = 0.0
-            s_scores = [round(float(cos[i, j] - self.special_w[j] + adj), 3) for j in range(ns)]
-            if any(v > 0 for v in s_scores):
-                adj = 0.01
+            s_scores = []
+            for j in range(ns):                        # upstream: the adjustment switches on inside this loop
+                s_scores.append(round(float(cos[i, j] - self.special_w[j] + adj), 3))
+                if s_scores[-1] > 0:
+                    adj = 0.01
             c_scores = [round(float(cos[i, ns + j] - self.concept_w[j] + adj), 3) for j in range(ncp)]
             flags.append(any(v > 0 for v in c_scores))
             cs.append(c_scores)
@@ -669,13 +680,22 @@ class SafetyChecker:
 
     @torch.no_grad()
     def forward(self, images_u8):
-        """device u8 [B,H,W,3] decoded images -> (images with flagged ones blacked out, has_nsfw list)."""
+        """device u8 [B,H,W,3] decoded images -> (the same tensor with flagged images blacked out IN PLACE, device int32
+        flags [B]).  No host round trip: the decision of `decide` runs in `saspa_safety_decide` (fp64, same order)."""
+        from . import _lib
         from .imageproc import clip_image_preprocess
+        import ctypes as C
+        if not images_u8.is_contiguous():
+            images_u8 = images_u8.contiguous()
+        b = images_u8.shape[0]
         px = clip_image_preprocess(images_u8, self.dtype, self.cfg["image_size"])
-        flags, _, _ = self.decide(*self.similarity(px))
-        if any(flags):
-            images_u8 = images_u8.clone()
-            for i, f in enumerate(flags):
-                if f:
-                    images_u8[i].zero_()           # upstream: black image
+        dots, gram = self.similarity(px)
+        flags = torch.empty((b,), device=images_u8.device, dtype=torch.int32)
+        lib = _lib.load()
+        _lib.check(lib.saspa_safety_decide(
+            C.c_void_p(dots.data_ptr()), dots.stride(0), C.c_void_p(gram.data_ptr()), gram.stride(0), b,
+            C.c_void_p(self.p["special_w"].data_ptr()), len(self.special_w), C.c_void_p(self.p["concept_w"].data_ptr()),
+            len(self.concept_w), C.c_double(self.round_threshold), C.c_void_p(images_u8.data_ptr()),
+            images_u8[0].numel(), C.c_void_p(flags.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "saspa_safety_decide")
         return images_u8, flags

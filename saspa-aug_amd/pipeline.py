@@ -109,7 +109,7 @@ class StableDiffusionControlNetPipeline:
         return self
 
     def run_safety_checker(self, images_u8):
-        """device u8 [B,H,W,3] -> (images with flagged ones replaced by black, has_nsfw_concept list | None)."""
+        """device u8 [B,H,W,3] -> (images with flagged ones replaced by black, device int32 flags [B] | None)."""
         if self.safety_checker is None:
             return images_u8, None
         return self.safety_checker.forward(images_u8)
@@ -235,7 +235,8 @@ class StableDiffusionControlNetPipeline:
         out = self.generate_batch(ids, neg, ctrl[None], lat, num_inference_steps, guidance_scale,
                                   controlnet_conditioning_scale)
         arr = out.cpu().numpy()
-        return PipelineOutput([Image.fromarray(a) for a in arr], self.last_nsfw)
+        nsfw = None if self.last_nsfw is None else [bool(v) for v in self.last_nsfw.cpu().tolist()]
+        return PipelineOutput([Image.fromarray(a) for a in arr], nsfw)
 
 
 class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):

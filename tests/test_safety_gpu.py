@@ -61,7 +61,7 @@ def test_safety_checker_tiny(dev, dtype):
     assert np.abs(gcs - cs).max() <= lim and np.abs(gss - ss).max() <= lim, (np.abs(gcs - cs).max(), np.abs(gss - ss).max())
     assert not any(flags) and gf == flags                    # synthetic thresholds sit 6 sigma out
     out, f2 = net.forward(torch.from_numpy(imgs).to(dev))
-    assert f2 == flags and np.array_equal(out.cpu().numpy(), imgs)
+    assert [bool(v) for v in f2.cpu().tolist()] == flags and np.array_equal(out.cpu().numpy(), imgs)
 
 
 def test_safety_checker_blacks_out_flagged_images(dev):
@@ -80,8 +80,11 @@ def test_safety_checker_blacks_out_flagged_images(dev):
     ref_out, ref_flags = OP.run_safety_checker(sd, cfg, imgs)
     assert 0 < sum(ref_flags) < len(ref_flags)
     net = models.SafetyChecker(sd, cfg, dev, torch.float32)
-    out, flags = net.forward(torch.from_numpy(imgs).to(dev))
-    assert flags == ref_flags and np.array_equal(out.cpu().numpy(), ref_out)
+    out, flags = net.forward(torch.from_numpy(imgs).to(dev))          # decision + black-out on the device
+    flags = [bool(v) for v in flags.cpu().tolist()]
+    host_flags, _, _ = net.decide(*net.similarity(IP.clip_image_preprocess(torch.from_numpy(imgs).to(dev), torch.float32,
+                                                                           cfg["image_size"])))
+    assert flags == ref_flags == host_flags and np.array_equal(out.cpu().numpy(), ref_out)
     assert all((out[i] == 0).all() for i, f in enumerate(flags) if f)
     # special-care concept firing adds 0.01 to every concept score of that image
     sd["special_care_embeds_weights"] = torch.full_like(sd["special_care_embeds_weights"], -10.0)
@@ -89,8 +92,11 @@ def test_safety_checker_blacks_out_flagged_images(dev):
     _, cs2, _ = IO.safety_checker_forward(sd, cfg, px)
     net2 = models.SafetyChecker(sd, cfg, dev, torch.float32)
     pxd = IP.clip_image_preprocess(torch.from_numpy(imgs).to(dev), torch.float32, cfg["image_size"])
-    _, gcs2, _ = net2.decide(*net2.similarity(pxd))
+    hf2, gcs2, _ = net2.decide(*net2.similarity(pxd))
     assert np.abs(np.asarray(gcs2) - cs2).max() <= 2e-3
+    # device decision with the adjustment on == the host replay of upstream's loop
+    _, df2 = net2.forward(torch.from_numpy(imgs).to(dev))
+    assert [bool(v) for v in df2.cpu().tolist()] == hf2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

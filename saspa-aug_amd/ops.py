@@ -112,6 +112,20 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     ho = (hv + 2 * pad - kh) // stride + 1
     wo = (wv + 2 * pad - kw) // stride + 1
     n = w.shape[0] if n_out is None else n_out
+    # geometry is validated HERE: the kernel trusts it (a mismatched skip / residual would be read out of bounds)
+    if x2 is not None and (tuple(x2.shape[:3]) != (b, h, wd) or x2.dtype != x.dtype):
+        raise ValueError(f"concat source {tuple(x2.shape)} does not match {tuple(x.shape)} (batch / height / width / dtype)")
+    if w.shape[1] < kh * kw * (c0 + c1) or w.dtype != x.dtype:
+        raise ValueError(f"weights {tuple(w.shape)} {w.dtype} do not fit a {kh}x{kw} window over {c0}+{c1} channels of {x.dtype}")
+    if ho <= 0 or wo <= 0:
+        raise ValueError("empty convolution output")
+    for name, t in (("residual", residual), ("out", out)):
+        if t is not None and (t.dim() != 4 or tuple(t.shape[:3]) != (b, ho, wo) or t.shape[3] < n or t.dtype != x.dtype):
+            raise ValueError(f"{name} {tuple(t.shape)} {t.dtype} does not match the output [{b},{ho},{wo},>={n}] {x.dtype}")
+    if bias is not None and bias.numel() < n:
+        raise ValueError("bias shorter than N")
+    if rowvec is not None and (rowvec.shape[-1] < n or (rowvec.dim() == 2 and rowvec.shape[0] not in (1, b))):
+        raise ValueError(f"rowvec {tuple(rowvec.shape)} must be [N] or [batch, N]")
     if out is None:
         nc = round8(n)
         out = (torch.zeros if nc != n else torch.empty)((b, ho, wo, nc), device=x.device, dtype=x.dtype)

@@ -190,8 +190,11 @@ class StableDiffusionControlNetPipeline:
         ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
         ctrl = ctrl.to(dev).contiguous()
         b, hh, ww, _ = ctrl.shape
-        if hh % 8 or ww % 8:
-            raise ValueError("control image sides must be multiples of 8")
+        mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
+        if hh % mult or ww % mult:
+            # the UNet halves the latent (H/8 x W/8) once per level below the first and doubles it back exactly; the
+            # reference only ever feeds multiples of 64 (all_utils/utils.py:65-77 rounds both sides to 64)
+            raise ValueError(f"control image sides must be multiples of {mult} (got {hh}x{ww})")
         want = (b, hh // 8, ww // 8, 8) if latents_on_device else (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
         if tuple(latents.shape) != want:
             raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")
@@ -431,8 +434,11 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
         ctrl = ctrl.to(dev).contiguous()
         b, hh, ww, _ = ctrl.shape
-        if hh % 8 or ww % 8:
-            raise ValueError("control image sides must be multiples of 8")
+        mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
+        if hh % mult or ww % mult:
+            # the UNet halves the latent (H/8 x W/8) once per level below the first and doubles it back exactly; the
+            # reference only ever feeds multiples of 64 (all_utils/utils.py:65-77 rounds both sides to 64)
+            raise ValueError(f"control image sides must be multiples of {mult} (got {hh}x{ww})")
         want = (b, hh // 8, ww // 8, 8) if latents_on_device else (b, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
         if tuple(latents.shape) != want:
             raise ValueError(f"latents shape {tuple(latents.shape)} does not match the control image {hh}x{ww}")

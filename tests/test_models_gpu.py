@@ -167,15 +167,18 @@ def test_pipeline_call_form(dev, tiny):
     from PIL import Image
     cfgs, fam = tiny
     pipe = StableDiffusionControlNetPipeline(fam, cfgs).to("cuda:0", torch.float16)
-    ctrl = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    ctrl = Image.fromarray(np.zeros((64, 128, 3), np.uint8))
     g = torch.manual_seed(1)
     a = pipe(prompt="an airplane on a runway", image=ctrl, num_inference_steps=3, generator=g, guidance_scale=7.5,
              negative_prompt="blurry", controlnet_conditioning_scale=0.75).images[0]
-    assert a.size == (96, 64) and a.mode == "RGB"
+    assert a.size == (128, 64) and a.mode == "RGB"
+    assert np.asarray(a).std() > 1.0                             # a real image, not a blacked-out / NaN frame
     g = torch.manual_seed(1)
     b = pipe(prompt="an airplane on a runway", image=ctrl, num_inference_steps=3, generator=g, guidance_scale=7.5,
              negative_prompt="blurry", controlnet_conditioning_scale=0.75).images[0]
     assert np.array_equal(np.asarray(a), np.asarray(b))          # deterministic given the seed
+    with pytest.raises(ValueError):                              # 96 is not a multiple of 64: the UNet cannot double back
+        pipe(prompt="x", image=Image.fromarray(np.zeros((64, 96, 3), np.uint8)), num_inference_steps=1)
     with pytest.raises(RuntimeError):
         StableDiffusionControlNetPipeline(fam, cfgs).to("cpu", torch.float32)
 

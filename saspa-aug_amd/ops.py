@@ -265,6 +265,12 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
     b, h, w, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
     ctot = c0 + c1
+    if x2 is not None and (tuple(x2.shape[:3]) != (b, h, w) or x2.dtype != x.dtype):
+        raise ValueError(f"concat source {tuple(x2.shape)} does not match {tuple(x.shape)}")
+    if gamma.numel() < ctot or beta.numel() < ctot or ctot % groups:
+        raise ValueError("GroupNorm parameters / groups do not match the channel count")
+    if out is not None and (tuple(out.shape[:3]) != (b, h, w) or out.shape[3] < ctot or out.dtype != x.dtype):
+        raise ValueError("GroupNorm output does not match the input geometry")
     if out is None:
         out = torch.empty((b, h, w, ctot), device=x.device, dtype=x.dtype)
     nsplit = _gn_nsplit(b, h * w, ctot // 8)

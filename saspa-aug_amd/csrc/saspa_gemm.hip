@@ -508,7 +508,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
 // beyond num_records and land as zeros.  Two LDS stages: the DMA of tile t+1 is in flight
 // during the MFMAs of tile t; one barrier per K-tile.
 
-template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE>
+// UP (nearest-x2 input) is a template parameter: as a run-time flag it put one scalar branch in front of every A-piece
+// DMA of every 3x3 conv's K-tile (4 per K-tile on the 128-row tile), and this issue path does not forgive branches.
+template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE, bool UP = false>
 __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 : 2) void gemm_dma_kernel(const SaspaGemmParams p,
                                                                                                       const int ntiles_abl) {
   // diagnostic ablation (tools/gemm_ablate.py only; 0 in production): bits 28..30 of the tile count
@@ -567,7 +569,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
   const rsrc_t rsw = make_rsrc(w);
   int bm = 0, bn = 0;
   int pix[A_CH], msk[A_CH], upc[A_CH];
-  const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
+  // !UP: byte offset of (pixel of row i, chunk kcs) in each source, fixed per tile -- the per-K-tile address of an A piece
+  // is then one add of the (wave-uniform) tap offset instead of a 64-bit multiply-add per piece and K-tile
+  unsigned offa0[A_CH], offa1[A_CH];
+  const int hv = UP ? 2 * p.hin : p.hin, wv = UP ? 2 * p.win : p.win;
   unsigned offb[B_CH];
   int ku = 0, cu = 0, dyu = 0, dxu = 0;
 
@@ -581,6 +586,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
         pix[i] = m;
         msk[i] = (m < p.M) ? 1 : 0;
         upc[i] = 0;
+        offa0[i] = (unsigned)(m * (p.lda0 * SZ) + kcs * 16);
+        offa1[i] = (unsigned)(m * (p.lda1 * SZ) + kcs * 16);
       }
     } else {
       int m = bm * BM + r0;
@@ -591,13 +598,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        if (p.upsample) {
+        if (UP) {
           // nearest x2: the window walks the virtual 2H x 2W grid; keep its top-left corner
           // (packed y | x) and resolve the source pixel ((iy0+dy)>>1, (ix0+dx)>>1) per tap
           pix[i] = b * p.hin * p.win;
           upc[i] = ((iy0 + 1) << 16) | (ix0 + 1);     // +1 keeps both halves non-negative (pad <= 1)
         } else {
           pix[i] = b * p.hin * p.win + (oy * p.stride) * p.win + ox * p.stride;
+          offa0[i] = (unsigned)(pix[i] * (p.lda0 * SZ) + kcs * 16);
+          offa1[i] = (unsigned)(pix[i] * (p.lda1 * SZ) + kcs * 16);
         }
         int mask = 0;
         if (m < p.M) {
@@ -641,16 +650,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
     const int soff = (s0 ? cu : cu - p.c0) * SZ;
     const int tapbit = dyu * p.kw + dxu;
     const int pixoff = PW ? 0 : (dyu - p.pad) * p.win + (dxu - p.pad);
+    const unsigned tapoff = (unsigned)(pixoff * ldsz);
     u32x4* la = lds + stage * STAGE;
     u32x4* lb = la + BM * 8;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      int px = pix[i] + pixoff;
-      if (!PW && p.upsample) {
+      unsigned off;
+      if (!PW && UP) {
         const int iy = ((upc[i] >> 16) - 1 + dyu) >> 1, ix = ((upc[i] & 0xffff) - 1 + dxu) >> 1;
-        px = pix[i] + iy * p.win + ix;
+        off = (unsigned)((pix[i] + iy * p.win + ix) * ldsz + kcs * 16);
+      } else {
+        off = (s0 ? offa0[i] : offa1[i]) + tapoff;      // == (pix + pixoff) * ldsz + kcs * 16 mod 2^32
       }
-      const unsigned off = (unsigned)(px * ldsz + kcs * 16);
       const bool ok = PW ? (msk[i] != 0) : (((msk[i] >> tapbit) & 1) != 0);
       if (BM % RPI == 0 || RPI * i + 8 * wave < BM)   // compile-time true for whole groups: no branch around the DMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(la + (RPI * i + 8 * wave) * 8), 16, (int)(ok ? off : kInvalid),
@@ -833,6 +844,7 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
     // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
     if (!fast) return SASPA_ERANGE;
     if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
+    else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3, true>), grid, dim3(NT), 0, s, p, tiles_abl);
     else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
   } else if (fast) {
     // few tiles (<= ~1 workgroup per CU): spend the idle LDS on a 4-deep DMA ring (latency-bound
@@ -842,9 +854,11 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
     const bool deep = can4 && (force_st ? force_st == 4 : (long long)tiles * zy <= 320);
     if (deep) {
       if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2, true>), grid, dim3(256), 0, s, p, tiles_abl);
       else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
     } else {
       if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2, true>), grid, dim3(256), 0, s, p, tiles_abl);
       else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles_abl);
     }
   } else {

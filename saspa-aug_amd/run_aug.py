@@ -409,14 +409,24 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     num_errors = 0
     pool = ThreadPoolExecutor(max_workers=4)
     futures = []
-    for batch in make_batches(mine, s.BATCH_SIZE):
+
+    def load_batch(batch):
+        """Decode + resize the batch's source (and subject) images: host work, prefetched one batch ahead on its own
+        thread so the GPU does not wait for JPEG decoding between launch sequences."""
+        srcs = np.stack([load_source(it.source_path, s.RESOLUTION) for it in batch])
+        subs = [load_source(it.subject_path, s.RESOLUTION) if it.subject_path else srcs[k] for k, it in enumerate(batch)] if blip else None
+        return srcs, subs
+
+    loader = ThreadPoolExecutor(max_workers=1)
+    batches = make_batches(mine, s.BATCH_SIZE)
+    pending = loader.submit(load_batch, batches[0]) if batches else None
+    for bi, batch in enumerate(batches):
         try:
-            sources = np.stack([load_source(it.source_path, s.RESOLUTION) for it in batch])
+            fut, pending = pending, (loader.submit(load_batch, batches[bi + 1]) if bi + 1 < len(batches) else None)
+            sources, subjects = fut.result()
             if blip:
-                subjects = [load_source(it.subject_path, s.RESOLUTION) if it.subject_path else sources[k] for k, it in enumerate(batch)]
                 images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources, subjects, ds_utils.meta_class)
             else:
-                subjects = None
                 images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources)
         except KeyboardInterrupt:
             raise
@@ -442,6 +452,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     for f in futures:
         f.result()
     pool.shutdown()
+    loader.shutdown()
 
     # ---- the one collective: per-item status vector -> rank 0 ----
     status = torch.zeros(len(items), dtype=torch.int32)

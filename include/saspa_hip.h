@@ -108,6 +108,11 @@ typedef struct SaspaGemmParams {
   int korder;
 } SaspaGemmParams;
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
+/* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):
+ * the caller allocates ksplit*M*N floats, sets p->ksplit / p->workspace and calls saspa_gemm.  Long-K layers with
+ * too few tiles to fill the chip get K slices (the 8-wave kernel on the 32x32 / 16x16 levels' 3x3 convs, the 4-wave
+ * tiles on the 8x8 level). */
+int saspa_gemm_suggest_ksplit(const SaspaGemmParams* p);
 
 /* ---- fused flash attention (bf16) -----------------------------------------
  * O[b][i][h*D+d] = sum_j softmax_j(scale * Q[b][i][h,:] . K[b][j][h,:]) * V[b][j][h,d]

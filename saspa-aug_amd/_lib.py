@@ -50,6 +50,7 @@ class GroupNormParams(C.Structure):
 _I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 SYMBOLS = {
     "saspa_gemm": (_I, [C.POINTER(GemmParams), _P]),
+    "saspa_gemm_suggest_ksplit": (_I, [C.POINTER(GemmParams)]),
     "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),

@@ -900,6 +900,10 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       if (fn) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
         if (t >= 192) return saspa_gemm_pp_launch(p, s, 1, fn);   // one wave of tiles or more: no split-K
+        // fewer wide tiles than CUs but a long K (the 3x3 convs of the 32x32 / 16x16 levels): the wide kernel on K
+        // slices -- measured 1.17-1.45x the 128x160 kernel at M = 16 384 / 4 096 (tools/conv_variant_sweep.py)
+        static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);   // A/B knob
+        if (wide_ks && ksplit > 1 && p.K >= 4096 && t >= 24 && t * ksplit >= 128) return saspa_gemm_pp_launch(p, s, ksplit, fn);
       }
     }
   } else {
@@ -912,6 +916,37 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// Recommended K-split of a problem (1 = none): the caller sizes the fp32 workspace (ksplit*M*N floats) from it.
+extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
+  if (!pp) return 1;
+  const SaspaGemmParams& p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (long long)p.nb1 * p.nb2 > 1 || p.N % 4 || p.act == SASPA_ACT_GEGLU) return 1;
+  const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
+  const int ktiles = (p.K + bk - 1) / bk;
+  static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);       // A/B knob
+  if (wide_ks && p.dtype == SASPA_BF16 && p.K >= 4096 && saspa_gemm_pp_eligible(p)) {
+    const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
+    if (fn) {
+      const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
+      if (t >= 192) return 1;                       // the wide kernel fills the chip without slicing K
+      if (t >= 24) {
+        int ks = (int)((256 + t / 2) / t);          // about one workgroup per CU
+        ks = ks < 2 ? 2 : (ks > 8 ? 8 : ks);
+        while (ks > 1 && ktiles / ks < 8) --ks;
+        if (ks > 1) return ks;
+      }
+    }
+  }
+  // 4-wave tiles: enough K slices to give the 256 CUs about two workgroups each, for the deep levels only
+  const int bn = (p.N % 160 == 0) ? 160 : 128;
+  const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+  if (p.N <= 64 || tiles >= 512 || ktiles < 32) return 1;
+  long long ks = (512 + tiles - 1) / tiles;
+  if (ks > 8) ks = 8;
+  if (ks > ktiles / 8) ks = ktiles / 8;
+  return ks < 1 ? 1 : (int)ks;
+}
 
 int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;

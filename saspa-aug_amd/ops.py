@@ -76,20 +76,11 @@ def round8(n):
     return (n + 7) // 8 * 8
 
 
-def _ksplit(m, n, k, dtype):
-    """Split-K factor for the deep UNet levels (M of 1-4 K rows, K of 6-23 K): enough K slices
-    to give the 256 CUs about two workgroups each; 1 (off) for everything else."""
-    bk = 64 if dtype == torch.bfloat16 else 32
-    bn = 160 if n % 160 == 0 else 128
-    tiles = -(-m // 128) * -(-n // bn)
-    ktiles = -(-k // bk)
-    if n <= 64 or n % 4 or tiles >= 512 or ktiles < 32:
-        return 1
-    return max(1, min(8, -(-512 // tiles), ktiles // 8))
-
-
-def _set_splitk(p, m, n, k, t):
-    ks = _ksplit(m, n, k, t.dtype)
+def _set_splitk(p, m, n, k, t, force=None):
+    """Split-K factor from the library's own heuristic (saspa_gemm_suggest_ksplit: every other field of p is already
+    filled in) or the caller's override; allocates the fp32 slab workspace."""
+    p.ksplit, p.workspace = 1, None
+    ks = _lib.load().saspa_gemm_suggest_ksplit(C.byref(p)) if force is None else int(force)
     if ks > 1:
         ws = torch.empty((ks * m * n,), device=t.device, dtype=torch.float32)
         p.ksplit, p.workspace = ks, C.c_void_p(ws.data_ptr())
@@ -99,7 +90,7 @@ def _set_splitk(p, m, n, k, t):
 
 
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
-         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None):
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
     (pad channels zero).  ``korder``: K order the weights were packed in (default: the tensor's
@@ -149,13 +140,13 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
     p.korder = int(getattr(w, "saspa_korder", 0)) if korder is None else int(korder)
-    _ws = _set_splitk(p, p.M, p.N, p.K, x)  # noqa: F841
+    _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
             (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0):
+def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0, ksplit=None):
     """x: [..., K] (last dim contiguous, uniform row pitch) @ w[N, K]^T -> [..., round8(N)]."""
     _check_dev(x, w, bias, residual, out)
     lib = _lib.load()
@@ -185,7 +176,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.ldo = o2.stride(0) if m > 1 else max(o2.shape[-1], o2.stride(0))
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
-    _ws = _set_splitk(p, m, n, k, x) if act != ACT_GEGLU else None  # noqa: F841
+    _ws = _set_splitk(p, m, n, k, x, ksplit) if act != ACT_GEGLU else None  # noqa: F841
     if act == ACT_GEGLU:
         p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),

@@ -200,6 +200,16 @@ int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg, long long
  * run_aug/run_aug.py:564-571; SURVEY 8a: a9). */
 int saspa_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, float sqrt_a_t,
                     float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev, void* stream);
+/* ---- device-side step state: ONE captured hipGraph of a sampling step serves every timestep -------------
+ * The per-step values a captured launch sequence cannot take as kernel arguments live in device tables indexed by a
+ * device-resident step counter: saspa_gather_row_f32 copies row *index of a [rows][row_elems] fp32 table into the
+ * buffer the time-embedding row vectors point into (dst[0..n)), saspa_ddim_step_dev is the (CFG +) DDIM update with
+ * its four coefficients read from row *index of coefs[steps][4] (cfg = 1: classifier-free guidance pair as
+ * saspa_cfg_ddim_step, 0: plain as saspa_ddim_step), saspa_index_add bumps the counter at the end of the step. */
+int saspa_gather_row_f32(const float* table, long long row_elems, const int* index, float* dst, long long n, void* stream);
+int saspa_ddim_step_dev(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, int cfg, float guidance,
+                        const float* coefs, const int* index, void* stream);
+int saspa_index_add(int* index, int delta, void* stream);
 /* y = x * s  (latents / scaling_factor before the VAE) */
 int saspa_scale(int dtype, const void* x, void* y, long long n, float s, void* stream);
 /* u8 RGB [n][H*W][3] -> [n][H*W][8] activations in [0,1], pad channels zero

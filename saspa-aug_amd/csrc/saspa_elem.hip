@@ -144,9 +144,16 @@ __global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hi
 
 // CFG + DDIM (eta = 0).  One item = one pixel (ldc == 8 channels, C live).
 // CFG == false: plain DDIM step on nimg samples (guidance off: SDXL-Turbo, run_aug/run_aug.py:568).
+// coefs != nullptr: the four coefficients come from row *index of a device table [steps][4] (hipGraph replays: one
+// captured step serves every timestep, the host only bumps the device-side step counter).
 template <typename T, bool CFG>
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* eps, T* x, int nimg, long long hw, int C, float g, float sa_t,
-                                                       float s1m_t, float sa_p, float s1m_p) {
+                                                       float s1m_t, float sa_p, float s1m_p, const float* coefs = nullptr,
+                                                       const int* index = nullptr) {
+  if (coefs) {
+    const float* c4 = coefs + 4ll * (*index);
+    sa_t = c4[0]; s1m_t = c4[1]; sa_p = c4[2]; s1m_p = c4[3];
+  }
   const long long total = (long long)nimg * hw;
   const long long half = total * 8;  // elements in one CFG half
   for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
@@ -320,6 +327,54 @@ extern "C" int saspa_ddim_step(int dtype, const void* eps, void* x, int nimg, lo
   return 0;
 }
 
+// ---- device-side step state for hipGraph replays of the sampling loop ----
+namespace {
+__global__ __launch_bounds__(256) void gather_row_kernel(const float* __restrict__ table, long long row_elems,
+                                                         const int* __restrict__ index, float* __restrict__ dst, long long n) {
+  const float* src = table + (long long)(*index) * row_elems;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < n; it += (long long)gridDim.x * 256) dst[it] = src[it];
+}
+__global__ void index_add_kernel(int* index, int delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *index += delta;
+}
+}  // namespace
+
+extern "C" int saspa_gather_row_f32(const float* table, long long row_elems, const int* index, float* dst, long long n,
+                                    void* stream) {
+  if (!table || !index || !dst || row_elems <= 0 || n <= 0 || n > row_elems) return SASPA_EINVAL;
+  hipLaunchKernelGGL(gather_row_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, row_elems,
+                     index, dst, n);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_index_add(int* index, int delta, void* stream) {
+  if (!index) return SASPA_EINVAL;
+  hipLaunchKernelGGL(index_add_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), index, delta);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_ddim_step_dev(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, int cfg,
+                                   float guidance, const float* coefs, const int* index, void* stream) {
+  if (!eps || !x || !coefs || !index || nimg <= 0 || hw <= 0 || C <= 0) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16) {
+    if (cfg) hipLaunchKernelGGL((cfg_ddim_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, guidance, 1.f, 0.f, 1.f, 0.f, coefs, index);
+    else hipLaunchKernelGGL((cfg_ddim_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, nimg, hw, C, 0.f, 1.f, 0.f, 1.f, 0.f, coefs, index);
+  } else if (dtype == SASPA_F32) {
+    if (cfg) hipLaunchKernelGGL((cfg_ddim_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, guidance, 1.f, 0.f, 1.f, 0.f, coefs, index);
+    else hipLaunchKernelGGL((cfg_ddim_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, nimg, hw, C, 0.f, 1.f, 0.f, 1.f, 0.f, coefs, index);
+  } else {
+    return SASPA_EINVAL;
+  }
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int saspa_scale(int dtype, const void* x, void* y, long long n, float sc, void* stream) {
   if (!x || !y || n <= 0) return SASPA_EINVAL;
   if (n % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
@@ -362,5 +417,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 6; }
+extern "C" int saspa_abi_version(void) { return 7; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

@@ -238,8 +238,28 @@ class _Net:
         else:
             shape = (e.shape[0], -1)
         se = ops.activation(e, SILU)
-        self.temb_tables = {pfx: ops.linear(se, p[pfx + ".time_emb_proj.w"], p[pfx + ".time_emb_proj.b"]).view(*shape)
-                            for pfx in self.resnets_with_temb}
+        # every resnet's time_emb_proj as ONE GEMM against the row-concatenated weights: table [steps(, B), total];
+        # resnet pfx owns the column block [off, off + Cout)
+        if "temb_cat.w" not in p:
+            p["temb_cat.w"] = torch.cat([p[pfx + ".time_emb_proj.w"] for pfx in self.resnets_with_temb], 0).contiguous()
+            p["temb_cat.b"] = torch.cat([p[pfx + ".time_emb_proj.b"] for pfx in self.resnets_with_temb], 0).contiguous()
+            self.temb_off, off = {}, 0
+            for pfx in self.resnets_with_temb:
+                c = p[pfx + ".time_emb_proj.w"].shape[0]
+                self.temb_off[pfx] = (off, c)
+                off += c
+            self.temb_total = off
+            for pfx in self.resnets_with_temb:                  # the per-resnet copies are no longer needed
+                del p[pfx + ".time_emb_proj.w"], p[pfx + ".time_emb_proj.b"]
+        tab = ops.linear(se, p["temb_cat.w"], p["temb_cat.b"])
+        self.temb_all = tab[:, :self.temb_total].contiguous().view(*shape[:-1], self.temb_total)
+        self.temb_tables = {pfx: self.temb_all[..., o:o + c] for pfx, (o, c) in self.temb_off.items()}
+
+    def bind_step_state(self, cur):
+        """hipGraph replays: `cur` ([total] or [B, total] fp32, one row of `temb_all`, refreshed on the device by
+        ops.gather_row) is what the resnets' row vectors point into when they are called with step=None."""
+        self.temb_cur = cur
+        self.temb_cur_views = {pfx: cur[..., o:o + c] for pfx, (o, c) in self.temb_off.items()}
 
     def prepare_context(self, ctx):
         """Cross-attention K and V^T of every transformer block for a [B,77,ctx_dim] batch."""
@@ -254,7 +274,9 @@ class _Net:
     # ---- blocks ----
     def resnet(self, pfx, x, step, eps, x2=None):
         p, g = self.p, self.cfg["groups"]
-        rv = self.temb_tables[pfx][step] if pfx in self.temb_tables else None
+        rv = None
+        if pfx in self.temb_tables:
+            rv = self.temb_cur_views[pfx] if step is None else self.temb_tables[pfx][step]
         h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
         h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv)
         h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU)

@@ -388,6 +388,35 @@ def ddim_step(eps, x, nimg, hw, c, sa_t, s1m_t, sa_p, s1m_p):
     return x
 
 
+def gather_row(table, index, dst):
+    """dst[:] = table[index[0]] for a [rows, ...] fp32 table and a device int32 index (hipGraph step state)."""
+    _check_dev(table, index, dst)
+    lib = _lib.load()
+    row = table[0].numel()
+    if table.dtype != torch.float32 or dst.dtype != torch.float32 or index.dtype != torch.int32 or not table.is_contiguous() \
+            or not dst.is_contiguous() or dst.numel() != row:
+        raise ValueError("gather_row: fp32 contiguous table [rows, ...], dst of one row, int32 index")
+    _lib.check(lib.saspa_gather_row_f32(_ptr(table), row, _ptr(index), _ptr(dst), row, _stream()), "saspa_gather_row_f32")
+    return dst
+
+
+def ddim_step_dev(eps, x, nimg, hw, c, guidance, coefs, index, cfg=True):
+    """(CFG +) DDIM update with the coefficients of row index[0] of the device table coefs [steps, 4]."""
+    _check_dev(eps, x, coefs, index)
+    lib = _lib.load()
+    if coefs.dtype != torch.float32 or coefs.dim() != 2 or coefs.shape[1] != 4 or not coefs.is_contiguous() or index.dtype != torch.int32:
+        raise ValueError("ddim_step_dev: coefs fp32 [steps, 4], int32 index")
+    _lib.check(lib.saspa_ddim_step_dev(_dt(x), _ptr(eps), _ptr(x), nimg, hw, c, 8, int(bool(cfg)), float(guidance), _ptr(coefs),
+                                       _ptr(index), _stream()), "saspa_ddim_step_dev")
+    return x
+
+
+def index_add(index, delta=1):
+    _check_dev(index)
+    _lib.check(_lib.load().saspa_index_add(_ptr(index), int(delta), _stream()), "saspa_index_add")
+    return index
+
+
 def scale(x, s, out=None):
     _check_dev(x, out)
     lib = _lib.load()

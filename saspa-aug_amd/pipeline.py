@@ -34,6 +34,93 @@ class PipelineOutput:
         self.nsfw_content_detected = nsfw_content_detected
 
 
+def graphs_enabled():
+    """hipGraph replay of the DDIM sampling step (default on; SASPA_GRAPH=0 launches every kernel from Python).  Off while
+    a launch recorder is installed (bench.py times individual launches with HIP events)."""
+    return os.environ.get("SASPA_GRAPH", "1") != "0" and ops._RECORDER is None
+
+
+class _DDIMStepGraph:
+    """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM update, ~1 500
+    kernel nodes -- replayed once per timestep.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
+    generation against 1.38 s of GPU time (tools/host_launch_time.py): the host was 7 % away from being the bottleneck.
+    Everything a step reads lives in static buffers owned by this object; what changes from step to step is read on the
+    device through a step counter (time-embedding rows: ops.gather_row; DDIM coefficients: ops.ddim_step_dev)."""
+
+    def __init__(self, pipe, x_shape, cemb_shape, ctx_shape, steps, cfg, guidance, cscale, added_shapes=None):
+        dev, dt = pipe.device, pipe.dtype
+        self.pipe, self.steps, self.cfg, self.guidance, self.cscale = pipe, steps, cfg, guidance, cscale
+        self.x = torch.zeros(x_shape, device=dev, dtype=dt)
+        self.eps = torch.zeros(x_shape, device=dev, dtype=dt)
+        self.cemb = torch.zeros(cemb_shape, device=dev, dtype=dt)
+        self.idx = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.coefs = torch.zeros((steps, 4), device=dev, dtype=torch.float32)
+        self.nets = (pipe.unet, pipe.controlnet)
+        self.tables, self.curs, self.ctx_kv = [], [], []
+        self.graph = None
+
+    def _bind(self):
+        """Point the networks at this graph's static state."""
+        for net, cur, kv in zip(self.nets, self.curs, self.ctx_kv):
+            net.bind_step_state(cur)
+            net.ctx_kv = kv
+
+    def load(self, x, cemb, ctx, ts, added=None):
+        """Refresh the static buffers for one generation (device-side copies; shapes are fixed by the cache key)."""
+        sch = self.pipe.scheduler
+        first = not self.tables
+        for i, net in enumerate(self.nets):
+            net.prepare_context(ctx)
+            net.prepare_timesteps(ts, added)
+            if first:
+                self.tables.append(net.temb_all.clone())
+                self.curs.append(torch.zeros_like(net.temb_all[0]))
+                self.ctx_kv.append({t: (k.clone(), vt.clone(), n) for t, (k, vt, n) in net.ctx_kv.items()})
+            else:
+                self.tables[i].copy_(net.temb_all)
+                for t, (k, vt, n) in net.ctx_kv.items():
+                    self.ctx_kv[i][t][0].copy_(k)
+                    self.ctx_kv[i][t][1].copy_(vt)
+        self.x.copy_(x)
+        self.cemb.copy_(cemb)
+        self.coefs.copy_(torch.tensor([sch.step_coefficients(t) for t in ts], dtype=torch.float32))
+        self.idx.zero_()
+        self._bind()
+
+    def _step(self):
+        pipe, x = self.pipe, self.x
+        for net, tab, cur in zip(self.nets, self.tables, self.curs):
+            ops.gather_row(tab, self.idx, cur)
+        mid, skips = pipe.unet.encode(x, None)
+        skips2, mid2 = pipe.controlnet.forward(x, None, self.cemb, self.cscale, skips, mid)
+        pipe.unet.decode(mid2, skips2, None, out=self.eps)
+        nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
+        ops.ddim_step_dev(self.eps, x, nimg, x.shape[1] * x.shape[2], pipe.cfgs["unet"]["out_channels"], self.guidance,
+                          self.coefs, self.idx, cfg=self.cfg)
+        ops.index_add(self.idx, 1)
+
+    def run_on(self, x, cemb, ctx, ts, added=None):
+        self.load(x, cemb, ctx, ts, added)
+        return self.run()
+
+    def run(self):
+        """All steps: the first generation on this object runs step 0 eagerly (warms allocator / lazy state), restores
+        the inputs, captures the step and replays; later generations only replay."""
+        if self.graph is None:
+            x0 = self.x.clone()
+            self._step()                                   # eager warm-up step (also validates every launch argument)
+            torch.cuda.synchronize()
+            self.x.copy_(x0)
+            self.idx.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step()
+            self.graph = g
+        for _ in range(self.steps):
+            self.graph.replay()
+        return self.x
+
+
 class StableDiffusionControlNetPipeline:
     def __init__(self, state_dicts, cfgs=SD15, tokenizer=None, scheduler=None):
         self._state_dicts = state_dicts
@@ -44,6 +131,7 @@ class StableDiffusionControlNetPipeline:
         self.dtype = None
         self.noise_dtype = None
         self.unet = self.controlnet = self.vae = self.text_encoder = None
+        self._graphs = {}                 # (shapes, steps, guidance, scale) -> _DDIMStepGraph, small LRU
         self.safety_checker = None        # built by .to() when the family ships one; assign None to disable (diffusers idiom)
         self.last_nsfw = None
         self._neg_cache = {}
@@ -145,6 +233,10 @@ class StableDiffusionControlNetPipeline:
         """The denoising loop on the CFG-doubled latents x2 [2B,h,w,8] (in place)."""
         sch = self.scheduler
         nc = self.cfgs["unet"]["out_channels"]
+        if not isinstance(sch, PNDMScheduler) and graphs_enabled():
+            ts = sch.set_timesteps(steps)
+            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale).run_on(x2, cemb2, ctx, ts))
+            return
         self.unet.prepare_context(ctx)
         self.controlnet.prepare_context(ctx)
         eps = torch.zeros_like(x2)
@@ -174,6 +266,16 @@ class StableDiffusionControlNetPipeline:
             for i, t in enumerate(ts):
                 evaluate(i)
                 ops.cfg_ddim_step(eps, x2, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
+
+    def _step_graph(self, x, cemb, ctx, steps, cfg, guidance, cscale):
+        key = (tuple(x.shape), tuple(cemb.shape), tuple(ctx.shape), int(steps), bool(cfg), float(guidance), float(cscale), x.dtype)
+        g = self._graphs.pop(key, None)
+        if g is None:
+            while len(self._graphs) >= 3:                   # each graph keeps one step's activations resident
+                self._graphs.pop(next(iter(self._graphs)))
+            g = _DDIMStepGraph(self, x.shape, cemb.shape, ctx.shape, steps, cfg, guidance, cscale)
+        self._graphs[key] = g                               # most recently used last
+        return g
 
     @torch.no_grad()
     def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps,
@@ -451,16 +553,20 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         x = (latents if latents_on_device else self.latents_to_device(latents)).contiguous()
         sch = self.scheduler
         ts = sch.set_timesteps(num_inference_steps)
-        for net in (self.unet, self.controlnet):
-            net.prepare_context(ctx)
-            net.prepare_timesteps(ts, (pooled, time_ids))
-        eps = torch.zeros_like(x)
-        nc, hw = self.cfgs["unet"]["out_channels"], (hh // 8) * (ww // 8)
-        for i, t in enumerate(ts):
-            mid, skips = self.unet.encode(x, i)
-            skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
-            self.unet.decode(mid2, skips2, i, out=eps)
-            ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))
+        if graphs_enabled():
+            g = self._step_graph(x, cemb, ctx, num_inference_steps, False, 0.0, controlnet_conditioning_scale)
+            x = g.run_on(x, cemb, ctx, ts, (pooled, time_ids)).clone()
+        else:
+            for net in (self.unet, self.controlnet):
+                net.prepare_context(ctx)
+                net.prepare_timesteps(ts, (pooled, time_ids))
+            eps = torch.zeros_like(x)
+            nc, hw = self.cfgs["unet"]["out_channels"], (hh // 8) * (ww // 8)
+            for i, t in enumerate(ts):
+                mid, skips = self.unet.encode(x, i)
+                skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
+                self.unet.decode(mid2, skips2, i, out=eps)
+                ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))
         z = ops.scale(x, 1.0 / self.cfgs["vae"]["scaling_factor"])
         if self.vae.dtype != z.dtype:
             z = z.to(self.vae.dtype)                      # upcast_vae(): latents follow the VAE dtype

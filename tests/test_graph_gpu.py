@@ -1,0 +1,94 @@
+"""hipGraph replay of the DDIM sampling step (pipeline._DDIMStepGraph): the captured step must reproduce the eager launch
+sequence bit for bit (same kernels, same order), across consecutive generations with different inputs (static buffers are
+refreshed), different step counts / shapes (new cache keys) and for the CFG-free SDXL-Turbo form."""
+import numpy as np
+import pytest
+import torch
+
+import saspa_aug_amd  # noqa: F401
+from saspa_aug_amd import config as CFG
+from saspa_aug_amd import ops
+from saspa_aug_amd import weights as W
+from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline, StableDiffusionXLControlNetPipeline, graphs_enabled
+from saspa_aug_amd.synthetic import synthetic_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(cfgs, n, hh, ww, seed):
+    rs = np.random.RandomState(seed)
+    ids = rs.randint(0, cfgs["text"]["vocab"] - 2, (n, 77))
+    neg = rs.randint(0, cfgs["text"]["vocab"] - 2, (1, 77))
+    ctrl = np.stack([(synthetic_image(hh, ww, seed + i) > 128).astype(np.uint8) * 255 for i in range(n)])
+    lat = torch.randn((n, 4, hh // 8, ww // 8), generator=torch.manual_seed(seed))
+    return ids, neg, ctrl, lat
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_replay_equals_eager_sd15(dev, dtype, monkeypatch):
+    cfgs = CFG.tiny()
+    fam = W.synth_family(cfgs, seed=3)
+    pipe = StableDiffusionControlNetPipeline(fam, cfgs).to(dev, dtype)
+    cases = [(2, 64, 64, 4, 11), (2, 64, 64, 4, 12), (1, 64, 128, 3, 13), (2, 64, 64, 6, 14), (2, 64, 64, 4, 15)]
+    monkeypatch.setenv("SASPA_GRAPH", "0")
+    assert not graphs_enabled()
+    eager = [pipe.generate_batch(*_inputs(cfgs, n, hh, ww, seed), steps, return_latents=True)[1].clone() for (n, hh, ww, steps, seed) in cases]
+    monkeypatch.setenv("SASPA_GRAPH", "1")
+    assert graphs_enabled()
+    for (n, hh, ww, steps, seed), ref in zip(cases, eager):
+        got = pipe.generate_batch(*_inputs(cfgs, n, hh, ww, seed), steps, return_latents=True)[1]
+        assert torch.equal(got, ref), f"graph replay differs from the eager loop for case {(n, hh, ww, steps, seed)}"
+    assert 1 <= len(pipe._graphs) <= 3 and all(g.graph is not None for g in pipe._graphs.values())
+    # a launch recorder (bench.py's roofline pass) turns the replay off
+    ops.set_recorder(lambda kind, flops, call, meta=None: call())
+    try:
+        assert not graphs_enabled()
+        got = pipe.generate_batch(*_inputs(cfgs, 2, 64, 64, 11), 4, return_latents=True)[1]
+        assert torch.equal(got, eager[0])
+    finally:
+        ops.set_recorder(None)
+
+
+def test_graph_replay_equals_eager_sdxl(dev, monkeypatch):
+    cfgs = CFG.tiny_xl()
+    fam = W.synth_family(cfgs, seed=3)
+    pipe = StableDiffusionXLControlNetPipeline(fam, cfgs).to(dev, torch.bfloat16)
+    v = cfgs["text"]["vocab"]
+
+    def inputs(n, seed):
+        rs = np.random.RandomState(seed)
+        ids = np.full((n, 77), v - 1, np.int64)
+        ids[:, 0] = v - 2
+        ids[:, 1:20] = rs.randint(0, v - 2, (n, 19))
+        ctrl = np.stack([(synthetic_image(64, 64, seed + i) > 128).astype(np.uint8) * 255 for i in range(n)])
+        return ids, None, ctrl, torch.randn((n, 4, 8, 8), generator=torch.manual_seed(seed))
+    monkeypatch.setenv("SASPA_GRAPH", "0")
+    eager = [pipe.generate_batch(*inputs(2, s), 2, return_latents=True)[1].clone() for s in (21, 22)]
+    monkeypatch.setenv("SASPA_GRAPH", "1")
+    for s, ref in zip((21, 22), eager):
+        assert torch.equal(pipe.generate_batch(*inputs(2, s), 2, return_latents=True)[1], ref)
+
+
+def test_step_state_kernels(dev):
+    tab = torch.arange(5 * 12, device=dev, dtype=torch.float32).view(5, 12)
+    idx = torch.tensor([3], device=dev, dtype=torch.int32)
+    cur = torch.zeros(12, device=dev)
+    ops.gather_row(tab, idx, cur)
+    assert torch.equal(cur, tab[3])
+    ops.index_add(idx, 1)
+    assert idx.item() == 4
+    # ddim_step_dev == cfg_ddim_step with the coefficients of the indexed row
+    g = torch.Generator().manual_seed(0)
+    eps = torch.randn(4, 6, 8, generator=g).to(dev)
+    x = torch.randn(4, 6, 8, generator=g).to(dev)
+    x[..., 4:] = 0
+    coefs = torch.tensor([[0.9, 0.4, 0.95, 0.3], [0.8, 0.6, 0.85, 0.5]], device=dev)
+    idx = torch.tensor([1], device=dev, dtype=torch.int32)
+    a, b = x.clone(), x.clone()
+    ops.cfg_ddim_step(eps, a, 2, 6, 4, 7.5, 0.8, 0.6, 0.85, 0.5)
+    ops.ddim_step_dev(eps, b, 2, 6, 4, 7.5, coefs, idx, cfg=True)
+    assert torch.equal(a, b)
+    a, b = x.clone(), x.clone()
+    ops.ddim_step(eps, a, 4, 6, 4, 0.8, 0.6, 0.85, 0.5)
+    ops.ddim_step_dev(eps, b, 4, 6, 4, 0.0, coefs, idx, cfg=False)
+    assert torch.equal(a, b)

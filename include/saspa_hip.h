@@ -159,10 +159,6 @@ typedef struct SaspaGroupNormParams {
 } SaspaGroupNormParams;
 int saspa_groupnorm_stats(const SaspaGroupNormParams* p, void* stream);
 int saspa_groupnorm_apply(const SaspaGroupNormParams* p, void* stream);
-/* stats + apply in one call, two launches: the apply kernel re-derives scale / shift of its image from the partial sums
- * in its prologue (fp64, LDS); `scale_shift` is only written by the three-launch fall-back (group counts that do not
- * divide 256, C > 6144). */
-int saspa_groupnorm(const SaspaGroupNormParams* p, void* stream);
 
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, CLIP LNs). */
 int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int C,

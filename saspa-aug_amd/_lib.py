@@ -55,7 +55,6 @@ SYMBOLS = {
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),
     "saspa_groupnorm_apply": (_I, [C.POINTER(GroupNormParams), _P]),
-    "saspa_groupnorm": (_I, [C.POINTER(GroupNormParams), _P]),
     "saspa_layernorm": (_I, [_I, _P, _I, _P, _I, _LL, _I, _P, _P, _F, _P]),
     "saspa_geglu": (_I, [_I, _P, _I, _P, _I, _LL, _I, _P]),
     "saspa_activation": (_I, [_I, _I, _P, _I, _P, _I, _LL, _I, _P]),

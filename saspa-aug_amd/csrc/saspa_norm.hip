@@ -141,87 +141,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
   }
 }
 
-// ---- apply with the finalize step inlined: grid (blocks per image, batch) ------------------
-// Every block first turns its image's partial sums into scale / shift for all C channels in LDS -- thread
-// (group g, slot s) adds the items s, s + SL, ... of group g in fp64, the SL slots of a group combine by a shuffle tree,
-// SL = 256 / groups -- then streams its share of the image's pixels.  One launch (and one dependent-kernel boundary)
-// less per GroupNorm than stats(partial + finalize) + apply; the ~2 us prologue runs concurrently in all blocks.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const SaspaGroupNormParams p) {
-  extern __shared__ __attribute__((aligned(16))) float scsh[];     // [2][C]
-  const int C = p.c0 + p.c1;
-  const int C8 = C >> 3;
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  {
-    const int SL = 256 / p.groups;                 // slots per group (power of two, <= 64: host-checked)
-    const int g = tid / SL, sl = tid - g * SL;
-    const int cpg = C / p.groups;
-    const int items = cpg * p.nsplit;
-    double s = 0.0, ss = 0.0;
-    for (int it = sl; it < items; it += SL) {
-      const int sp = it / cpg, cj = it - sp * cpg;
-      const float* src = p.partial + (((long long)b * p.nsplit + sp) * C + g * cpg + cj) * 2;
-      s += (double)src[0];
-      ss += (double)src[1];
-    }
-    for (int o = SL >> 1; o > 0; o >>= 1) {
-      s += __shfl_xor(s, o, 64);
-      ss += __shfl_xor(ss, o, 64);
-    }
-    const double n = (double)cpg * (double)p.hw;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    const float meanf = (float)mean;
-    for (int cj = sl; cj < cpg; cj += SL) {
-      const int ch = g * cpg + cj;
-      const float ga = p.gamma[ch] * rstd;
-      scsh[ch] = ga;
-      scsh[C + ch] = p.beta[ch] - meanf * ga;
-    }
-  }
-  __syncthreads();
-  const long long total = (long long)p.hw * C8;    // items of this image
-  const long long pix0 = (long long)b * p.hw;
-  for (long long it = (long long)blockIdx.x * 256 + tid; it < total; it += (long long)gridDim.x * 256) {
-    const long long pl = it / C8;
-    const int chunk = (int)(it - pl * C8);
-    const long long pix = pix0 + pl;
-    const int ch = chunk * 8;
-    const T* src;
-    int ld, cc;
-    if (ch < p.c0) { src = reinterpret_cast<const T*>(p.x0); ld = p.ldx0; cc = ch; }
-    else { src = reinterpret_cast<const T*>(p.x1); ld = p.ldx1; cc = ch - p.c0; }
-    const T* ptr = src + pix * ld + cc;
-    float v[8];
-    if constexpr (sizeof(T) == 2) {
-      Elem<T>::load_chunk(ptr, v);
-    } else {
-      Elem<T>::load_chunk(ptr, v);
-      Elem<T>::load_chunk(ptr + 4, v + 4);
-    }
-    const float4 s0 = *reinterpret_cast<const float4*>(scsh + ch), s1 = *reinterpret_cast<const float4*>(scsh + ch + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(scsh + C + ch), h1 = *reinterpret_cast<const float4*>(scsh + C + ch + 4);
-    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float y = v[j] * scv[j] + shv[j];
-      if (p.act == SASPA_ACT_SILU) y = silu_f(y);
-      v[j] = y;
-    }
-    T* dst = reinterpret_cast<T*>(p.y) + pix * p.ldy + ch;
-    if constexpr (sizeof(T) == 2) {
-      Elem<T>::store_chunk(dst, v);
-    } else {
-      Elem<T>::store_chunk(dst, v);
-      Elem<T>::store_chunk(dst + 4, v + 4);
-    }
-  }
-}
-
 // ---- LayerNorm: one wave per row, two-pass in registers ---------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, int ldx, T* y, int ldy, long long rows, int C,
@@ -325,40 +244,6 @@ extern "C" int saspa_groupnorm_apply(const SaspaGroupNormParams* pp, void* strea
   if (blocks > 8192) blocks = 8192;
   if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  SASPA_CHECK_LAUNCH();
-  return 0;
-}
-
-// statistics + apply as ONE call: partial sums, then the apply kernel with the finalize step inlined (two launches
-// instead of three); falls back to the three-launch form for group counts that do not divide 256 or very wide C.
-extern "C" int saspa_groupnorm(const SaspaGroupNormParams* pp, void* stream) {
-  if (!pp) return SASPA_EINVAL;
-  const SaspaGroupNormParams& p = *pp;
-  if (int e = check_gn(p)) return e;
-  if (!p.y || p.ldy % 8 || !aligned16(p.y)) return SASPA_EALIGN;
-  const int C = p.c0 + p.c1;
-  const int sl = (p.groups <= 256 && 256 % p.groups == 0) ? 256 / p.groups : 0;
-  if (sl == 0 || sl > 64 || (size_t)2 * C * sizeof(float) > 48 * 1024) {
-    if (int e = saspa_groupnorm_stats(pp, stream)) return e;
-    return saspa_groupnorm_apply(pp, stream);
-  }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int C8 = C / 8;
-  const int cxw = C8 >= 32 ? 32 : 16;
-  const int slabs = (C8 + cxw - 1) / cxw;
-  const int pps = (p.hw + p.nsplit - 1) / p.nsplit;
-  dim3 grid(p.nsplit, p.batch, slabs);
-  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), 0, s, p, cxw, pps);
-  else hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, p, cxw, pps);
-  SASPA_CHECK_LAUNCH();
-  const long long per_img = (long long)p.hw * C8;
-  long long bx = (per_img + 255) / 256;
-  const long long cap = 8192 / p.batch > 0 ? 8192 / p.batch : 1;
-  if (bx > cap) bx = cap;
-  if (bx < 1) bx = 1;
-  const size_t lds = (size_t)2 * C * sizeof(float);
-  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_apply_fused_kernel<bf16_t>, dim3((unsigned)bx, p.batch), dim3(256), lds, s, p);
-  else hipLaunchKernelGGL(gn_apply_fused_kernel<float>, dim3((unsigned)bx, p.batch), dim3(256), lds, s, p);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

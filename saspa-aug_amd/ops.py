@@ -22,7 +22,6 @@ GEMM_AUTO, GEMM_TILED, GEMM_WIDE = 0, 1, 2   # SaspaGemmParams.variant
 # and must return call()'s result.  `flops` is the ALGORITHMIC work of the launch (2*M*N*K
 # for the implicit GEMM, 4*nq*nk*D per head for attention), used for the roofline figures.
 _RECORDER = None
-_GN_FUSED = __import__("os").environ.get("SASPA_GN_FUSED", "1") != "0"
 
 
 def set_recorder(rec):
@@ -277,12 +276,9 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
     p.gamma, p.beta = _ptr(gamma), _ptr(beta)
     p.partial, p.nsplit, p.scale_shift = _ptr(partial), nsplit, _ptr(ss)
     p.act, p.y, p.ldy = int(act), _ptr(out), _pitch4(out)
-    if _GN_FUSED:
-        _lib.check(lib.saspa_groupnorm(C.byref(p), _stream()), "saspa_groupnorm")      # partial sums + apply (finalize inlined)
-    else:                                                                                # A/B knob SASPA_GN_FUSED=0
-        s = _stream()
-        _lib.check(lib.saspa_groupnorm_stats(C.byref(p), s), "saspa_groupnorm_stats")
-        _lib.check(lib.saspa_groupnorm_apply(C.byref(p), s), "saspa_groupnorm_apply")
+    s = _stream()
+    _lib.check(lib.saspa_groupnorm_stats(C.byref(p), s), "saspa_groupnorm_stats")
+    _lib.check(lib.saspa_groupnorm_apply(C.byref(p), s), "saspa_groupnorm_apply")
     return out
 
 

@@ -210,6 +210,11 @@ int saspa_gather_row_f32(const float* table, long long row_elems, const int* ind
 int saspa_ddim_step_dev(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc, int cfg, float guidance,
                         const float* coefs, const int* index, void* stream);
 int saspa_index_add(int* index, int delta, void* stream);
+/* saspa_cfg_plms_step with its per-evaluation parameters read from row *index of table[evaluations][10] =
+ * (store_slot, w_cur, w_hist[4], coef_sample, coef_model, save_sample, use_saved): the evaluation with save_sample copies
+ * x into `saved` ([nimg][hw][ldc]) before the update, the one with use_saved reads it instead of x. */
+int saspa_cfg_plms_step_dev(int dtype, const void* eps, void* x, void* hist, void* saved, int nimg, long long hw, int C, int ldc,
+                            float guidance, const float* table, const int* index, void* stream);
 /* y = x * s  (latents / scaling_factor before the VAE) */
 int saspa_scale(int dtype, const void* x, void* y, long long n, float s, void* stream);
 /* u8 RGB [n][H*W][3] -> [n][H*W][8] activations in [0,1], pad channels zero

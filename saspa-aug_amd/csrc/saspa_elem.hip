@@ -108,18 +108,30 @@ __global__ __launch_bounds__(256) void embed_tokens_ctx_kernel(const int* ids, i
 
 // CFG + one linear multistep (PNDM / PLMS) update.  e = eu + g (ec - eu) is optionally stored in the history
 // ring; m = w_cur e + sum_k w[k] hist[k]; x' = cx * s + cm * m with s = the saved sample or x itself.
+// table != nullptr (hipGraph replays): the step's parameters are row *index of a device table [evaluations][10] =
+// (store_slot, w_cur, w_hist[4], coef_sample, coef_model, save_sample, use_saved); `saved` is then a real buffer: the
+// step with save_sample copies x into it before the update, the step with use_saved reads it instead of x.
 template <typename T>
 __global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hist, const T* sample, int nimg, long long hw, int C,
                                                        float g, int store_slot, float w_cur, float w0, float w1, float w2, float w3,
-                                                       float cx, float cm) {
+                                                       float cx, float cm, const float* table = nullptr, const int* index = nullptr,
+                                                       T* saved = nullptr) {
   const long long total = (long long)nimg * hw;
   const long long half = total * 8;
+  bool save = false;
+  if (table) {
+    const float* r = table + 10ll * (*index);
+    store_slot = (int)r[0]; w_cur = r[1]; w0 = r[2]; w1 = r[3]; w2 = r[4]; w3 = r[5]; cx = r[6]; cm = r[7];
+    save = r[8] != 0.f;
+    sample = (r[9] != 0.f) ? saved : nullptr;
+  }
   const float w[4] = {w0, w1, w2, w3};
   for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
     float eu[8], ec[8], sv[8], e[8], m[8], o[8];
     load8(eps + it * 8, eu);
     load8(eps + half + it * 8, ec);
     load8((sample ? sample : x) + it * 8, sv);
+    if (save) store8(saved + it * 8, sv);           // sv is x here (a saving step never reads the saved sample)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       e[j] = eu[j] + g * (ec[j] - eu[j]);
@@ -290,6 +302,23 @@ extern "C" int saspa_cfg_plms_step(int dtype, const void* eps, void* x, void* hi
   return 0;
 }
 
+extern "C" int saspa_cfg_plms_step_dev(int dtype, const void* eps, void* x, void* hist, void* saved, int nimg, long long hw, int C,
+                                       int ldc, float guidance, const float* table, const int* index, void* stream) {
+  if (!eps || !x || !hist || !saved || !table || !index || nimg <= 0 || hw <= 0 || C <= 0) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x) || !aligned16(hist) || !aligned16(saved)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(cfg_plms_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, (bf16_t*)hist, (const bf16_t*)nullptr, nimg, hw, C, guidance, -1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, table, index, (bf16_t*)saved);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(cfg_plms_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, (float*)hist, (const float*)nullptr, nimg, hw, C, guidance, -1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, table, index, (float*)saved);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int saspa_cfg_ddim_step(int dtype, const void* eps, void* x, int nimg, long long hw, int C, int ldc,
                                    float guidance, float sqrt_a_t, float sqrt_1m_a_t, float sqrt_a_prev,
                                    float sqrt_1m_a_prev, void* stream) {
@@ -417,5 +446,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 7; }
+extern "C" int saspa_abi_version(void) { return 8; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

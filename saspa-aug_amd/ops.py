@@ -411,6 +411,16 @@ def ddim_step_dev(eps, x, nimg, hw, c, guidance, coefs, index, cfg=True):
     return x
 
 
+def cfg_plms_step_dev(eps, x, hist, saved, nimg, hw, c, guidance, table, index):
+    """PLMS update with the evaluation's parameters read from row index[0] of the device table [evaluations, 10]."""
+    _check_dev(eps, x, hist, saved, table, index)
+    if table.dtype != torch.float32 or table.dim() != 2 or table.shape[1] != 10 or not table.is_contiguous() or index.dtype != torch.int32:
+        raise ValueError("cfg_plms_step_dev: table fp32 [evaluations, 10], int32 index")
+    _lib.check(_lib.load().saspa_cfg_plms_step_dev(_dt(x), _ptr(eps), _ptr(x), _ptr(hist), _ptr(saved), nimg, hw, c, 8, float(guidance),
+                                                   _ptr(table), _ptr(index), _stream()), "saspa_cfg_plms_step_dev")
+    return x
+
+
 def index_add(index, delta=1):
     _check_dev(index)
     _lib.check(_lib.load().saspa_index_add(_ptr(index), int(delta), _stream()), "saspa_index_add")

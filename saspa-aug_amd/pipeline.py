@@ -40,9 +40,9 @@ def graphs_enabled():
     return os.environ.get("SASPA_GRAPH", "1") != "0" and ops._RECORDER is None
 
 
-class _DDIMStepGraph:
-    """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM update, ~1 500
-    kernel nodes -- replayed once per timestep.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
+class _StepGraph:
+    """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM or PLMS update,
+    ~1 500 kernel nodes -- replayed once per network evaluation.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
     generation against 1.38 s of GPU time (tools/host_launch_time.py): the host was 7 % away from being the bottleneck.
     Everything a step reads lives in static buffers owned by this object; what changes from step to step is read on the
     device through a step counter (time-embedding rows: ops.gather_row; DDIM coefficients: ops.ddim_step_dev)."""
@@ -54,7 +54,15 @@ class _DDIMStepGraph:
         self.eps = torch.zeros(x_shape, device=dev, dtype=dt)
         self.cemb = torch.zeros(cemb_shape, device=dev, dtype=dt)
         self.idx = torch.zeros((1,), device=dev, dtype=torch.int32)
-        self.coefs = torch.zeros((steps, 4), device=dev, dtype=torch.float32)
+        self.plms = isinstance(pipe.scheduler, PNDMScheduler)
+        if self.plms:       # N + 1 evaluations; per-evaluation parameters, the 4-slot history ring and the saved sample
+            self.evals = steps + 1
+            self.coefs = torch.zeros((self.evals, 10), device=dev, dtype=torch.float32)
+            self.hist = torch.zeros((4, x_shape[0] // 2) + tuple(x_shape[1:]), device=dev, dtype=dt)
+            self.saved = torch.zeros((x_shape[0] // 2,) + tuple(x_shape[1:]), device=dev, dtype=dt)
+        else:
+            self.evals = steps
+            self.coefs = torch.zeros((steps, 4), device=dev, dtype=torch.float32)
         self.nets = (pipe.unet, pipe.controlnet)
         self.tables, self.curs, self.ctx_kv = [], [], []
         self.graph = None
@@ -83,7 +91,13 @@ class _DDIMStepGraph:
                     self.ctx_kv[i][t][1].copy_(vt)
         self.x.copy_(x)
         self.cemb.copy_(cemb)
-        self.coefs.copy_(torch.tensor([sch.step_coefficients(t) for t in ts], dtype=torch.float32))
+        if self.plms:
+            rows = [[d["store_slot"], d["w_cur"], *d["w_hist"], d["coef_sample"], d["coef_model"], float(d["save_sample"]),
+                     float(d["use_saved"])] for d in self.plan]
+            self.coefs.copy_(torch.tensor(rows, dtype=torch.float32))
+            self.hist.zero_()
+        else:
+            self.coefs.copy_(torch.tensor([sch.step_coefficients(t) for t in ts], dtype=torch.float32))
         self.idx.zero_()
         self._bind()
 
@@ -95,11 +109,15 @@ class _DDIMStepGraph:
         skips2, mid2 = pipe.controlnet.forward(x, None, self.cemb, self.cscale, skips, mid)
         pipe.unet.decode(mid2, skips2, None, out=self.eps)
         nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
-        ops.ddim_step_dev(self.eps, x, nimg, x.shape[1] * x.shape[2], pipe.cfgs["unet"]["out_channels"], self.guidance,
-                          self.coefs, self.idx, cfg=self.cfg)
+        nc, hw = pipe.cfgs["unet"]["out_channels"], x.shape[1] * x.shape[2]
+        if self.plms:
+            ops.cfg_plms_step_dev(self.eps, x, self.hist, self.saved, nimg, hw, nc, self.guidance, self.coefs, self.idx)
+        else:
+            ops.ddim_step_dev(self.eps, x, nimg, hw, nc, self.guidance, self.coefs, self.idx, cfg=self.cfg)
         ops.index_add(self.idx, 1)
 
-    def run_on(self, x, cemb, ctx, ts, added=None):
+    def run_on(self, x, cemb, ctx, ts, added=None, plan=None):
+        self.plan = plan
         self.load(x, cemb, ctx, ts, added)
         return self.run()
 
@@ -112,11 +130,13 @@ class _DDIMStepGraph:
             torch.cuda.synchronize()
             self.x.copy_(x0)
             self.idx.zero_()
+            if self.plms:
+                self.hist.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step()
             self.graph = g
-        for _ in range(self.steps):
+        for _ in range(self.evals):
             self.graph.replay()
         return self.x
 
@@ -131,7 +151,7 @@ class StableDiffusionControlNetPipeline:
         self.dtype = None
         self.noise_dtype = None
         self.unet = self.controlnet = self.vae = self.text_encoder = None
-        self._graphs = {}                 # (shapes, steps, guidance, scale) -> _DDIMStepGraph, small LRU
+        self._graphs = {}                 # (shapes, steps, guidance, scale) -> _StepGraph, small LRU
         self.safety_checker = None        # built by .to() when the family ships one; assign None to disable (diffusers idiom)
         self.last_nsfw = None
         self._neg_cache = {}
@@ -233,9 +253,13 @@ class StableDiffusionControlNetPipeline:
         """The denoising loop on the CFG-doubled latents x2 [2B,h,w,8] (in place)."""
         sch = self.scheduler
         nc = self.cfgs["unet"]["out_channels"]
-        if not isinstance(sch, PNDMScheduler) and graphs_enabled():
-            ts = sch.set_timesteps(steps)
-            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale).run_on(x2, cemb2, ctx, ts))
+        if graphs_enabled():
+            if isinstance(sch, PNDMScheduler):
+                plan = sch.plan(steps)                 # N+1 evaluations, the second timestep twice
+                ts, plan = [t for t, _ in plan], [d for _, d in plan]
+            else:
+                ts, plan = sch.set_timesteps(steps), None
+            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale).run_on(x2, cemb2, ctx, ts, plan=plan))
             return
         self.unet.prepare_context(ctx)
         self.controlnet.prepare_context(ctx)
@@ -268,12 +292,13 @@ class StableDiffusionControlNetPipeline:
                 ops.cfg_ddim_step(eps, x2, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
 
     def _step_graph(self, x, cemb, ctx, steps, cfg, guidance, cscale):
-        key = (tuple(x.shape), tuple(cemb.shape), tuple(ctx.shape), int(steps), bool(cfg), float(guidance), float(cscale), x.dtype)
+        key = (tuple(x.shape), tuple(cemb.shape), tuple(ctx.shape), int(steps), bool(cfg), float(guidance), float(cscale), x.dtype,
+               type(self.scheduler).__name__)
         g = self._graphs.pop(key, None)
         if g is None:
             while len(self._graphs) >= 3:                   # each graph keeps one step's activations resident
                 self._graphs.pop(next(iter(self._graphs)))
-            g = _DDIMStepGraph(self, x.shape, cemb.shape, ctx.shape, steps, cfg, guidance, cscale)
+            g = _StepGraph(self, x.shape, cemb.shape, ctx.shape, steps, cfg, guidance, cscale)
         self._graphs[key] = g                               # most recently used last
         return g
 

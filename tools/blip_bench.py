@@ -27,6 +27,7 @@ t0 = time.time(); n = 2
 for _ in range(n): out = once()
 torch.cuda.synchronize(); dt = (time.time() - t0) / n
 out2 = once()
+torch.cuda.synchronize()
 t1 = time.time(); q = pipe.get_query_embeddings(subjects, ["bird"] * b); torch.cuda.synchronize(); tq = time.time() - t1
 print(json.dumps({"workload": "BLIP-Diffusion + Canny ControlNet, batch=8 512x512, %d PLMS steps (BASELINE configs[2])" % steps,
                   "images_per_s": round(b / dt, 4), "s_per_batch": round(dt, 3), "front_end_ms_per_batch": round(tq * 1e3, 1),

@@ -338,7 +338,10 @@ def hip_batch_generator(pipe, s: Settings):
 
     blip = "blip_diffusion" in s.BASE_MODEL
 
-    def run(batch, noises, sources, subjects=None, category=None):
+    side = torch.cuda.Stream(device=pipe.device)
+
+    def enqueue(batch, noises, sources, subjects=None, category=None):
+        """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU."""
         src = torch.from_numpy(np.ascontiguousarray(sources)).to(pipe.device)
         ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
         lat = torch.cat(noises)
@@ -353,7 +356,25 @@ def hip_batch_generator(pipe, s: Settings):
             ids = np.concatenate([tok(it.prompt) for it in batch])
             out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
                                       s.CONTROLNET_CONDITIONING_SCALE)
-        return out.cpu().numpy(), ctrl.cpu().numpy()
+        ev = torch.cuda.Event()
+        ev.record()
+        return out, ctrl, ev
+
+    def finish(handle):
+        """Device -> host copies of a batch enqueued earlier, on a side stream that waits for THAT batch only: the next
+        batch's launch sequence may already be queued behind it on the main stream and keeps the GPU busy meanwhile."""
+        out, ctrl, ev = handle
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            out.record_stream(side)
+            ctrl.record_stream(side)
+            o, c = out.cpu(), ctrl.cpu()
+        return o.numpy(), c.numpy()
+
+    def run(batch, noises, sources, subjects=None, category=None):
+        return finish(enqueue(batch, noises, sources, subjects, category))
+
+    run.enqueue, run.finish = enqueue, finish
     return run
 
 
@@ -420,25 +441,28 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     loader = ThreadPoolExecutor(max_workers=1)
     batches = make_batches(mine, s.BATCH_SIZE)
     pending = loader.submit(load_batch, batches[0]) if batches else None
-    for bi, batch in enumerate(batches):
+    # software pipeline over batches: batch i+1 is enqueued on the GPU BEFORE batch i's images are copied back and handed
+    # to the PNG pool, so the GPU never waits for host-side post-processing (injected test generators run synchronously)
+    pipelined = hasattr(batch_generator, "enqueue") and hasattr(batch_generator, "finish")
+    inflight = None
+
+    def failed(batch, e):
+        nonlocal num_errors
+        logging.exception(e)                 # the reference treats RuntimeError as OOM (:493-500); isolate per batch
+        num_errors += 1
+        for it in batch:
+            it.status = -1
+
+    def drain(entry):
+        batch, handle, sources, subjects = entry
         try:
-            fut, pending = pending, (loader.submit(load_batch, batches[bi + 1]) if bi + 1 < len(batches) else None)
-            sources, subjects = fut.result()
-            if blip:
-                images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources, subjects, ds_utils.meta_class)
-            else:
-                images, controls = batch_generator(batch, [noises[it.order] for it in batch], sources)
-        except KeyboardInterrupt:
-            raise
-        except RuntimeError as e:            # the reference treats RuntimeError as OOM (:493-500); isolate per batch
-            logging.exception(e)
-            num_errors += 1
-            for it in batch:
-                it.status = -1
-            if num_errors > 20:
-                logging.info("Too many errors, stopping generation on this rank")
-                break
-            continue
+            images, controls = batch_generator.finish(handle)
+        except RuntimeError as e:
+            failed(batch, e)
+            return
+        emit(batch, images, controls, sources, subjects)
+
+    def emit(batch, images, controls, sources, subjects):
         for k, it in enumerate(batch):
             stem40 = it.image_stem[:MAX_FILENAME_LENGTH]
             if first_variant[it.index] == it.order:
@@ -449,6 +473,32 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
                 futures.append(pool.submit(Image.fromarray(subjects[k]).save, os.path.join(output_folder, f"{stem40}_subject_{it.i}.png")))
             futures.append(pool.submit(Image.fromarray(images[k]).save, it.output_path))
             it.status = 1
+
+    for bi, batch in enumerate(batches):
+        try:
+            fut, pending = pending, (loader.submit(load_batch, batches[bi + 1]) if bi + 1 < len(batches) else None)
+            sources, subjects = fut.result()
+            args = (batch, [noises[it.order] for it in batch], sources) + ((subjects, ds_utils.meta_class) if blip else ())
+            if pipelined:
+                handle = batch_generator.enqueue(*args)
+            else:
+                images, controls = batch_generator(*args)
+        except KeyboardInterrupt:
+            raise
+        except RuntimeError as e:
+            failed(batch, e)
+            if num_errors > 20:
+                logging.info("Too many errors, stopping generation on this rank")
+                break
+            continue
+        if pipelined:
+            if inflight is not None:
+                drain(inflight)
+            inflight = (batch, handle, sources, subjects)
+        else:
+            emit(batch, images, controls, sources, subjects)
+    if inflight is not None:
+        drain(inflight)
     for f in futures:
         f.result()
     pool.shutdown()

@@ -94,7 +94,7 @@ class Blip2QFormer:
         b, _, s, _ = pixel_values.shape
         ps, vw = cfg["patch"], cfg["vis_width"]
         g = s // ps
-        x = pixel_values.to(self.dev, self.dtype)
+        x = ops.h2d(pixel_values, self.dev, self.dtype)
         patches = x.reshape(b, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(b * g * g, 3 * ps * ps)
         kpad = p["patch.w"].shape[1] - patches.shape[1]
         if kpad:
@@ -149,7 +149,7 @@ class Blip2QFormer:
         nq, w = cfg["num_query"], cfg["width"]
         image_embeds = self.vision(pixel_values)
         ids = torch.as_tensor(np.asarray(input_ids)) if not torch.is_tensor(input_ids) else input_ids
-        txt = ops.embed_tokens(ids.to(self.dev), p["word"], p["tpos"], t).view(b, t, w)
+        txt = ops.embed_tokens(ops.h2d(ids, self.dev), p["word"], p["tpos"], t).view(b, t, w)
         x = torch.cat([p["query_tokens"].expand(b, -1, -1), txt], 1).contiguous()
         x = ops.layernorm(x, p["embeddings.LayerNorm.g"], p["embeddings.LayerNorm.b"], cfg["eps"])
         for i in range(cfg["layers"]):

@@ -216,7 +216,7 @@ class _Net:
         coefficients (Timesteps(dim0, flip_sin_to_cos=True, freq_shift=0)).
         SDXL (`add_embed` in the config): `added` = (text_embeds [B, pooled] device fp32, time_ids [B, 6] host) adds
         the per-sample text_time embedding, so the tables become [steps, B, Cout] (row vector per batch sample)."""
-        sinus = self._sinusoid(timesteps, self.cfg["block_out"][0]).to(self.dev)
+        sinus = ops.h2d(self._sinusoid(timesteps, self.cfg["block_out"][0]), self.dev)
         p = self.p
         e = ops.linear(sinus, p["time_embedding.linear_1.w"], p["time_embedding.linear_1.b"], act=SILU)
         e = ops.linear(e, p["time_embedding.linear_2.w"], p["time_embedding.linear_2.b"])       # [S, temb]
@@ -226,7 +226,7 @@ class _Net:
             text_embeds, time_ids = added
             ae = self.cfg["add_embed"]
             b = text_embeds.shape[0]
-            te = self._sinusoid(torch.as_tensor(time_ids, dtype=torch.float32), ae["time_dim"]).reshape(b, -1).to(self.dev)
+            te = ops.h2d(self._sinusoid(torch.as_tensor(time_ids, dtype=torch.float32), ae["time_dim"]).reshape(b, -1), self.dev)
             a_in = torch.cat([text_embeds.to(torch.float32), te], -1).contiguous()
             a = ops.linear(a_in, p["add_embedding.linear_1.w"], p["add_embedding.linear_1.b"], act=SILU)
             # emb[s][b] = time_emb[s] + aug[b]: the aug row block is the GEMM's residual, once per step

@@ -57,6 +57,18 @@ def _check_dev(*ts):
             raise RuntimeError("saspa_aug_amd ops run on the GPU only (tensor is on %s)" % t.device)
 
 
+def h2d(t, device, dtype=None):
+    """Host -> device copy that does NOT block the host: through pinned memory, asynchronous in the current stream (a
+    pageable-memory copy would wait for everything queued before it -- e.g. the previous batch's whole launch sequence --
+    and defeat the batch pipeline of run_aug).  Device tensors pass through."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    if t.is_cuda:
+        return t if dtype is None or t.dtype == dtype else t.to(dtype)
+    d = t.contiguous().pin_memory().to(device, non_blocking=True)
+    return d if dtype is None or d.dtype == dtype else d.to(dtype)
+
+
 def _pitch4(x):
     """[B,H,W,C] channels-last view -> pixel pitch; validates regular pixel rows."""
     b, h, w, c = x.shape

@@ -77,26 +77,30 @@ class _StepGraph:
         """Refresh the static buffers for one generation (device-side copies; shapes are fixed by the cache key)."""
         sch = self.pipe.scheduler
         first = not self.tables
+        refresh_t = first or added is not None          # without SDXL's added conditioning the time tables depend on ts only
         for i, net in enumerate(self.nets):
             net.prepare_context(ctx)
-            net.prepare_timesteps(ts, added)
+            if refresh_t:
+                net.prepare_timesteps(ts, added)
             if first:
                 self.tables.append(net.temb_all.clone())
                 self.curs.append(torch.zeros_like(net.temb_all[0]))
                 self.ctx_kv.append({t: (k.clone(), vt.clone(), n) for t, (k, vt, n) in net.ctx_kv.items()})
             else:
-                self.tables[i].copy_(net.temb_all)
+                if refresh_t:
+                    self.tables[i].copy_(net.temb_all)
                 for t, (k, vt, n) in net.ctx_kv.items():
                     self.ctx_kv[i][t][0].copy_(k)
                     self.ctx_kv[i][t][1].copy_(vt)
         self.x.copy_(x)
         self.cemb.copy_(cemb)
         if self.plms:
-            rows = [[d["store_slot"], d["w_cur"], *d["w_hist"], d["coef_sample"], d["coef_model"], float(d["save_sample"]),
-                     float(d["use_saved"])] for d in self.plan]
-            self.coefs.copy_(torch.tensor(rows, dtype=torch.float32))
+            if first:
+                rows = [[d["store_slot"], d["w_cur"], *d["w_hist"], d["coef_sample"], d["coef_model"], float(d["save_sample"]),
+                         float(d["use_saved"])] for d in self.plan]
+                self.coefs.copy_(torch.tensor(rows, dtype=torch.float32))
             self.hist.zero_()
-        else:
+        elif first:
             self.coefs.copy_(torch.tensor([sch.step_coefficients(t) for t in ts], dtype=torch.float32))
         self.idx.zero_()
         self._bind()
@@ -232,7 +236,7 @@ class StableDiffusionControlNetPipeline:
         self._need_device()
         if not torch.is_tensor(ids):
             ids = torch.as_tensor(np.asarray(ids))
-        return self.text_encoder.forward(ids.to(self.device))
+        return self.text_encoder.forward(ops.h2d(ids, self.device))
 
     def _negative_context(self, neg_ids):
         key = np.asarray(neg_ids).tobytes()
@@ -244,7 +248,7 @@ class StableDiffusionControlNetPipeline:
         """[B,4,h,w] noise (any float dtype, CPU) -> channels-last [B,h,w,8] in compute dtype."""
         x = latents.to(torch.float32).permute(0, 2, 3, 1)
         x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1]))
-        return (x * self.scheduler.init_noise_sigma).to(self.device, self.dtype).contiguous()
+        return ops.h2d((x * self.scheduler.init_noise_sigma).contiguous(), self.device, self.dtype).contiguous()
 
     def _positive_context(self, prompt_ids, query_embeds=None):
         return self.encode_prompts(prompt_ids)
@@ -315,7 +319,7 @@ class StableDiffusionControlNetPipeline:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) belongs to the SDXL-Turbo branch (SURVEY a9)")
         dev, dt = self.device, self.dtype
         ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
-        ctrl = ctrl.to(dev).contiguous()
+        ctrl = ops.h2d(ctrl, dev).contiguous()
         b, hh, ww, _ = ctrl.shape
         mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
         if hh % mult or ww % mult:
@@ -439,7 +443,7 @@ class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
         ids = torch.as_tensor(np.asarray(prompt_ids)) if not torch.is_tensor(prompt_ids) else prompt_ids
         if ids.shape[1] != self.prompt_token_count():
             raise ValueError(f"prompt must be tokenised to {self.prompt_token_count()} tokens (77 - subject tokens)")
-        return self.text_encoder.forward(ids.to(self.device), query_embeds, self.cfgs["ctx_begin_pos"])
+        return self.text_encoder.forward(ops.h2d(ids, self.device), query_embeds, self.cfgs["ctx_begin_pos"])
 
     # ---- the reference's call form (keyword names as diffusers spells them, typo included) ----
     def __call__(self, prompt=None, reference_image=None, condtioning_image=None, source_subject_category=None,
@@ -542,7 +546,7 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
     def encode_prompts_xl(self, ids1, ids2):
         """-> (context [B,77,ctx1+ctx2], pooled [B, proj] fp32)."""
         self._need_device()
-        t = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(self.device)   # noqa: E731
+        t = lambda a: ops.h2d(a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)), self.device)   # noqa: E731
         h1, _ = self.text_encoder.forward(t(ids1), penultimate=True)
         h2, pooled = self.text_encoder_2.forward(t(ids2), penultimate=True)
         return torch.cat([h1, h2], -1).contiguous(), pooled.float()
@@ -559,7 +563,7 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
                                       "CFG for SDXL is not built")
         dev, dt = self.device, self.dtype
         ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
-        ctrl = ctrl.to(dev).contiguous()
+        ctrl = ops.h2d(ctrl, dev).contiguous()
         b, hh, ww, _ = ctrl.shape
         mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
         if hh % mult or ww % mult:

@@ -342,7 +342,7 @@ def hip_batch_generator(pipe, s: Settings):
 
     def enqueue(batch, noises, sources, subjects=None, category=None):
         """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU."""
-        src = torch.from_numpy(np.ascontiguousarray(sources)).to(pipe.device)
+        src = ops.h2d(torch.from_numpy(np.ascontiguousarray(sources)), pipe.device)
         ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
         lat = torch.cat(noises)
         if blip:
@@ -474,15 +474,21 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
             futures.append(pool.submit(Image.fromarray(images[k]).save, it.output_path))
             it.status = 1
 
+    import time as _time
+    prof = os.environ.get("SASPA_PROFILE_LOOP") == "1"          # per-batch host timings in the log (diagnostics)
     for bi, batch in enumerate(batches):
         try:
+            t0 = _time.time()
             fut, pending = pending, (loader.submit(load_batch, batches[bi + 1]) if bi + 1 < len(batches) else None)
             sources, subjects = fut.result()
+            t1 = _time.time()
             args = (batch, [noises[it.order] for it in batch], sources) + ((subjects, ds_utils.meta_class) if blip else ())
             if pipelined:
                 handle = batch_generator.enqueue(*args)
             else:
                 images, controls = batch_generator(*args)
+            if prof:
+                print(f"[loop] batch {bi}: wait for sources {t1 - t0:.3f} s, enqueue {_time.time() - t1:.3f} s", flush=True)
         except KeyboardInterrupt:
             raise
         except RuntimeError as e:
@@ -493,7 +499,10 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
             continue
         if pipelined:
             if inflight is not None:
+                t2 = _time.time()
                 drain(inflight)
+                if prof:
+                    print(f"[loop] batch {bi}: drain of the previous batch {_time.time() - t2:.3f} s", flush=True)
             inflight = (batch, handle, sources, subjects)
         else:
             emit(batch, images, controls, sources, subjects)

@@ -27,7 +27,15 @@ for sizes in (((512, 512),), ((512, 704),)):
     res = R.main(s, pipe=pipe)
     torch.cuda.synchronize(); dt = time.time() - t0
     n = int((res["status"] == 1).sum())
-    print(json.dumps({"workload": f"run_aug.main end to end, synthetic dataset {n_images} images x 4 variants at {sizes[0][0]}x{sizes[0][1]}, "
-                                  f"{steps} DDIM steps, batch 8, PNG I/O + safety checker + JSON included",
-                      "images": n, "seconds": round(dt, 2), "images_per_s": round(n / dt, 3), "dtype": "bf16", "data": "synthetic"}), flush=True)
+    # a second, 3x longer run on a fresh dataset: the slope between the two is the steady-state rate (planning, the first
+    # load, the final PNG flush and the JSON are per-run constants)
+    s3 = R.Settings(**{**s.__dict__, "DATASET_KWARGS": dict(root_path=root + "_x3", n_images=3 * n_images, sizes=sizes)})
+    torch.cuda.synchronize(); t0 = time.time()
+    res3 = R.main(s3, pipe=pipe)
+    torch.cuda.synchronize(); dt3 = time.time() - t0
+    n3 = int((res3["status"] == 1).sum())
+    print(json.dumps({"workload": f"run_aug.main end to end, synthetic dataset {n_images} / {3 * n_images} images x 4 variants at "
+                                  f"{sizes[0][0]}x{sizes[0][1]}, {steps} DDIM steps, batch 8, PNG I/O + safety checker + JSON included",
+                      "images": [n, n3], "seconds": [round(dt, 2), round(dt3, 2)], "images_per_s": [round(n / dt, 3), round(n3 / dt3, 3)],
+                      "steady_state_images_per_s": round((n3 - n) / (dt3 - dt), 3), "dtype": "bf16", "data": "synthetic"}), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)

@@ -49,6 +49,41 @@ CONTROLNET_DICT_SD = {"canny": "lllyasviel/control_v11p_sd15_canny", "hed": "lll
 CONTROLNET_DICT_SD_XL = {"canny": "diffusers/controlnet-canny-sdxl-1.0"}
 
 
+def _save_png(arr, path):
+    Image.fromarray(arr).save(path)
+
+
+class _PngWriters:
+    """PNG encoding off the launch thread.  Pillow's encoder holds the GIL (4 encoding threads cut the main thread's
+    Python throughput to 27 %: measured), and the main thread is what enqueues the GPU work, so the writers are forked
+    worker PROCESSES (they only ever touch numpy / Pillow); SASPA_PNG_PROCS=0 selects the old thread pool."""
+
+    def __init__(self, workers=4):
+        n = int(os.environ.get("SASPA_PNG_PROCS", workers))
+        self.pending = []
+        if n > 0:
+            import multiprocessing
+            self.pool, self.threads = multiprocessing.get_context("fork").Pool(n), None
+        else:
+            self.pool, self.threads = None, ThreadPoolExecutor(max_workers=workers)
+
+    def submit(self, arr, path):
+        arr = np.ascontiguousarray(arr)
+        if self.pool is not None:
+            self.pending.append(self.pool.apply_async(_save_png, (arr, str(path))))
+        else:
+            self.pending.append(self.threads.submit(_save_png, arr, str(path)))
+
+    def close(self):
+        for f in self.pending:
+            f.get() if self.pool is not None else f.result()
+        if self.pool is not None:
+            self.pool.close()
+            self.pool.join()
+        else:
+            self.threads.shutdown()
+
+
 @dataclass
 class Settings:
     """The module-level constants of the reference's `__main__` block (run_aug/run_aug.py:513-556)."""
@@ -390,6 +425,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     builds the HIP pipeline (fails loudly without an MI355X)."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
+    png = _PngWriters(4)                      # forked first, before this process starts any thread of its own
     utils.set_seed(s.SEED)
     if ds_utils is None:
         ds_utils = dataset_utils.DS_UTILS_DICT[s.DATASET](**s.DATASET_KWARGS)
@@ -428,8 +464,6 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     for it in items:
         first_variant.setdefault(it.index, it.order)
     num_errors = 0
-    pool = ThreadPoolExecutor(max_workers=4)
-    futures = []
 
     def load_batch(batch):
         """Decode + resize the batch's source (and subject) images: host work, prefetched one batch ahead on its own
@@ -466,12 +500,12 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
         for k, it in enumerate(batch):
             stem40 = it.image_stem[:MAX_FILENAME_LENGTH]
             if first_variant[it.index] == it.order:
-                futures.append(pool.submit(Image.fromarray(sources[k]).save, os.path.join(output_folder, f"{stem40}_source.png")))
+                png.submit(sources[k], os.path.join(output_folder, f"{stem40}_source.png"))
                 if it.index < 10:
-                    futures.append(pool.submit(Image.fromarray(controls[k]).save, f"{output_folder}/{stem40}_control.png"))
+                    png.submit(controls[k], f"{output_folder}/{stem40}_control.png")
             if subjects is not None and it.subject_path:     # :453-454 "_subject_{i}.png" (excluded from the JSON by name)
-                futures.append(pool.submit(Image.fromarray(subjects[k]).save, os.path.join(output_folder, f"{stem40}_subject_{it.i}.png")))
-            futures.append(pool.submit(Image.fromarray(images[k]).save, it.output_path))
+                png.submit(subjects[k], os.path.join(output_folder, f"{stem40}_subject_{it.i}.png"))
+            png.submit(images[k], it.output_path)
             it.status = 1
 
     import time as _time
@@ -508,9 +542,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
             emit(batch, images, controls, sources, subjects)
     if inflight is not None:
         drain(inflight)
-    for f in futures:
-        f.result()
-    pool.shutdown()
+    png.close()
     loader.shutdown()
 
     # ---- the one collective: per-item status vector -> rank 0 ----

@@ -55,33 +55,68 @@ def _save_png(arr, path):
 
 class _PngWriters:
     """PNG encoding off the launch thread.  Pillow's encoder holds the GIL (4 encoding threads cut the main thread's
-    Python throughput to 27 %: measured), and the main thread is what enqueues the GPU work, so the writers are forked
-    worker PROCESSES (they only ever touch numpy / Pillow); SASPA_PNG_PROCS=0 selects the old thread pool."""
+    Python throughput to 27 %: measured), and the main thread is what enqueues the GPU work, so the writers are separate
+    PROCESSES: `png_worker.py` children started with subprocess (no fork of this -- large, GPU-holding -- process image,
+    nothing but numpy / Pillow in the children), each fed through its stdin by a feeder thread (pipe writes release the
+    GIL).  SASPA_PNG_PROCS=0 selects the old in-process thread pool."""
 
     def __init__(self, workers=4):
+        import queue
+        import subprocess
+        import sys
+        import threading
         n = int(os.environ.get("SASPA_PNG_PROCS", workers))
-        self.pending = []
-        if n > 0:
-            import multiprocessing
-            self.pool, self.threads = multiprocessing.get_context("fork").Pool(n), None
-        else:
-            self.pool, self.threads = None, ThreadPoolExecutor(max_workers=workers)
+        self.procs, self.queues, self.feeders, self.next = [], [], [], 0
+        self.threads, self.pending = None, []
+        if n <= 0:
+            self.threads = ThreadPoolExecutor(max_workers=workers)
+            return
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "png_worker.py")
+
+        def feed(proc, q):
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                header, data = item
+                proc.stdin.write(header)
+                proc.stdin.write(data)
+            proc.stdin.close()
+
+        for _ in range(n):
+            proc = subprocess.Popen([sys.executable, script], stdin=subprocess.PIPE)
+            q = queue.Queue()
+            t = threading.Thread(target=feed, args=(proc, q), daemon=True)
+            t.start()
+            self.procs.append(proc)
+            self.queues.append(q)
+            self.feeders.append(t)
 
     def submit(self, arr, path):
-        arr = np.ascontiguousarray(arr)
-        if self.pool is not None:
-            self.pending.append(self.pool.apply_async(_save_png, (arr, str(path))))
-        else:
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        if self.threads is not None:
             self.pending.append(self.threads.submit(_save_png, arr, str(path)))
+            return
+        h, w = arr.shape[:2]
+        c = arr.shape[2] if arr.ndim == 3 else 1
+        if "\n" in str(path):
+            raise ValueError("newline in an output path")
+        self.queues[self.next].put((f"{h} {w} {c} {path}\n".encode("utf-8"), arr.tobytes()))
+        self.next = (self.next + 1) % len(self.queues)
 
     def close(self):
-        for f in self.pending:
-            f.get() if self.pool is not None else f.result()
-        if self.pool is not None:
-            self.pool.close()
-            self.pool.join()
-        else:
+        if self.threads is not None:
+            for f in self.pending:
+                f.result()
             self.threads.shutdown()
+            return
+        for q in self.queues:
+            q.put(None)
+        for t in self.feeders:
+            t.join()
+        codes = [p.wait() for p in self.procs]
+        if any(codes):
+            raise RuntimeError(f"PNG writer processes exited with {codes}")
 
 
 @dataclass
@@ -425,7 +460,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     builds the HIP pipeline (fails loudly without an MI355X)."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
-    png = _PngWriters(4)                      # forked first, before this process starts any thread of its own
+    png = _PngWriters(4)
     utils.set_seed(s.SEED)
     if ds_utils is None:
         ds_utils = dataset_utils.DS_UTILS_DICT[s.DATASET](**s.DATASET_KWARGS)

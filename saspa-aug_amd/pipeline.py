@@ -47,7 +47,7 @@ class _StepGraph:
     Everything a step reads lives in static buffers owned by this object; what changes from step to step is read on the
     device through a step counter (time-embedding rows: ops.gather_row; DDIM coefficients: ops.ddim_step_dev)."""
 
-    def __init__(self, pipe, x_shape, cemb_shape, ctx_shape, steps, cfg, guidance, cscale, added_shapes=None):
+    def __init__(self, pipe, x_shape, cemb_shape, steps, cfg, guidance, cscale):
         dev, dt = pipe.device, pipe.dtype
         self.pipe, self.steps, self.cfg, self.guidance, self.cscale = pipe, steps, cfg, guidance, cscale
         self.x = torch.zeros(x_shape, device=dev, dtype=dt)
@@ -263,7 +263,7 @@ class StableDiffusionControlNetPipeline:
                 ts, plan = [t for t, _ in plan], [d for _, d in plan]
             else:
                 ts, plan = sch.set_timesteps(steps), None
-            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale).run_on(x2, cemb2, ctx, ts, plan=plan))
+            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale, ts).run_on(x2, cemb2, ctx, ts, plan=plan))
             return
         self.unet.prepare_context(ctx)
         self.controlnet.prepare_context(ctx)
@@ -295,14 +295,15 @@ class StableDiffusionControlNetPipeline:
                 evaluate(i)
                 ops.cfg_ddim_step(eps, x2, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
 
-    def _step_graph(self, x, cemb, ctx, steps, cfg, guidance, cscale):
+    def _step_graph(self, x, cemb, ctx, steps, cfg, guidance, cscale, ts):
+        # the timesteps are part of the key: the cached time tables / coefficients follow the scheduler's configuration
         key = (tuple(x.shape), tuple(cemb.shape), tuple(ctx.shape), int(steps), bool(cfg), float(guidance), float(cscale), x.dtype,
-               type(self.scheduler).__name__)
+               type(self.scheduler).__name__, tuple(int(t) for t in ts))
         g = self._graphs.pop(key, None)
         if g is None:
             while len(self._graphs) >= 3:                   # each graph keeps one step's activations resident
                 self._graphs.pop(next(iter(self._graphs)))
-            g = _StepGraph(self, x.shape, cemb.shape, ctx.shape, steps, cfg, guidance, cscale)
+            g = _StepGraph(self, x.shape, cemb.shape, steps, cfg, guidance, cscale)
         self._graphs[key] = g                               # most recently used last
         return g
 
@@ -583,7 +584,7 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         sch = self.scheduler
         ts = sch.set_timesteps(num_inference_steps)
         if graphs_enabled():
-            g = self._step_graph(x, cemb, ctx, num_inference_steps, False, 0.0, controlnet_conditioning_scale)
+            g = self._step_graph(x, cemb, ctx, num_inference_steps, False, 0.0, controlnet_conditioning_scale, ts)
             x = g.run_on(x, cemb, ctx, ts, (pooled, time_ids)).clone()
         else:
             for net in (self.unet, self.controlnet):

@@ -224,3 +224,38 @@ def test_pipeline_refuses_cpu():
         xl.to("cpu", torch.float16)
     with pytest.raises(NotImplementedError):
         R.init_pipeline("blip_diffusion", "canny", 1)       # SDEdit is a baseline branch
+
+
+def test_png_writer_processes_write_what_pillow_reads(tmp_path):
+    """run_aug's PNG writers are png_worker.py child processes fed through pipes (Pillow's encoder holds the GIL): the
+    files must decode to exactly the submitted pixels, for RGB and single-channel arrays and paths with spaces."""
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, (40 + 8 * i, 64, 3)).astype(np.uint8) for i in range(6)] + [rs.randint(0, 256, (32, 48)).astype(np.uint8)]
+    for procs in ("3", "0"):
+        os.environ["SASPA_PNG_PROCS"] = procs
+        try:
+            w = R._PngWriters(3)
+            paths = [tmp_path / f"w{procs} img {i}_prompt_a photo, of x_{i}.png" for i in range(len(imgs))]
+            for im, pth in zip(imgs, paths):
+                w.submit(im, pth)
+            w.close()
+        finally:
+            del os.environ["SASPA_PNG_PROCS"]
+        for im, pth in zip(imgs, paths):
+            assert np.array_equal(np.asarray(Image.open(pth)), im)
+
+
+def test_chunk_major_packing_is_the_documented_permutation():
+    from saspa_aug_amd import weights as W
+    co, ci, taps = 5, 128, 9
+    w = torch.arange(co * ci * taps, dtype=torch.float32).reshape(co, ci, 3, 3)
+    tap_major = W.pack_conv(w)                                   # K = tap * C + c
+    for dtype, bk in ((torch.bfloat16, 64), (torch.float32, 32)):
+        assert W.ktile(dtype) == bk and W.chunk_major_ok(3, 3, ci, 0, dtype) and not W.chunk_major_ok(1, 1, ci, 0, dtype)
+        cm = W.to_chunk_major(tap_major, taps, dtype)            # K = (chunk * taps + tap) * bk + c_in_chunk
+        for n in (0, 4):
+            for chunk in range(ci // bk):
+                for tap in (0, 4, 8):
+                    for c in (0, bk - 1):
+                        assert cm[n, (chunk * taps + tap) * bk + c] == tap_major[n, tap * ci + chunk * bk + c] == w[n, chunk * bk + c, tap // 3, tap % 3]
+    assert not W.chunk_major_ok(3, 3, 96, 0, torch.bfloat16) and W.chunk_major_ok(3, 3, 96, 32, torch.float32)

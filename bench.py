@@ -24,17 +24,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import saspa_aug_amd  # noqa: E402,F401
-from saspa_aug_amd import config as CFG  # noqa: E402
-from saspa_aug_amd import ops  # noqa: E402
-from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline  # noqa: E402
-from saspa_aug_amd.synthetic import negative_prompt_ids, synthetic_image, synthetic_prompt_ids  # noqa: E402
+# NOTE: torch / the package are imported inside the functions that need them: the `--gpus N` launcher below must start
+# its N rank processes BEFORE anything in this (parent) process can touch the GPU.
 
 BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
 F_IMG_50 = 109.33e12               # algorithmic FLOP / 512x512 image at 50 steps
@@ -48,6 +42,7 @@ class Recorder:
         self.items = []
 
     def __call__(self, kind, flops, call, meta=None):
+        import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = call()
@@ -55,11 +50,26 @@ class Recorder:
         self.items.append((kind, flops, e0, e1, meta))
         return r
 
-    def summary(self):
+    @staticmethod
+    def classify(kind, meta):
+        """Launch class for `roofline.by_class`: the implicit-GEMM launches split by window (meta =
+        (M, N, K, kh, stride, upsample, concat); kh < 0 marks the batched raw GEMMs: V^T projections, unfused attention)."""
+        if kind != "gemm" or meta is None:
+            return kind
+        kh = meta[3]
+        if kh == 3:
+            return "conv3x3"
+        if kh < 0:
+            return "batched_gemm"
+        return "pointwise_linear" if kh in (0, 1) else "conv_other"
+
+    def summary(self, by_class=False):
+        import torch
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1, _ in self.items:
-            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+        for kind, flops, e0, e1, meta in self.items:
+            key = self.classify(kind, meta) if by_class else kind
+            d = out.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += e0.elapsed_time(e1)
@@ -82,8 +92,12 @@ def cpu_baseline(seconds_budget=15.0):
     """Oracle (torch fp32 on the usable host cores) on a BOUNDED sample of the same workload:
     repeated UNet+ControlNet CFG evaluations of one 512x512 image (each 2.167 TFLOP incl. the
     conditioning embedding the un-hoisted oracle recomputes) until ~seconds_budget of CPU work;
-    extrapolated by FLOPs to one 50-step image (109.33 TFLOP)."""
+    EXTRAPOLATED by FLOPs to one 50-step image (109.33 TFLOP).  The directly timed BASELINE configs[0] run
+    (1 image, 10 steps, whole pipeline) is `--baselines full` -> profiles/r2_baselines_full.json."""
+    import torch
+
     from oracle import sd_models as OM
+    from saspa_aug_amd import config as CFG
     from saspa_aug_amd import weights as W
     cores = effective_cpus()
     torch.set_num_threads(cores)
@@ -103,11 +117,153 @@ def cpu_baseline(seconds_budget=15.0):
             n += 1
     dt = (time.time() - t0) / n
     sec_per_image = dt * (F_IMG_50 / step_flop)
-    return dict(value=round(1.0 / sec_per_image, 6), unit="images/s", cores=cores, kind="port",
+    return dict(value=round(1.0 / sec_per_image, 6), unit="images/s", cores=cores, kind="port", extrapolated=True,
                 sample=f"{n} UNet+ControlNet CFG evaluations (batch 2, 512x512, torch fp32 oracle), {dt:.2f} s each on "
-                       f"{cores} threads (cgroup quota; os.cpu_count()={os.cpu_count()}), scaled by 109.33 TFLOP / "
+                       f"{cores} threads (cgroup quota; os.cpu_count()={os.cpu_count()}), EXTRAPOLATED by 109.33 TFLOP / "
                        f"{step_flop / 1e12:.3f} TFLOP to one 50-step image",
                 cpu_tflops=round(step_flop / dt / 1e12, 3))
+
+
+def baselines_full(dev):
+    """SURVEY 8(d) comparators, `--baselines full` only (minutes of work; the result is committed under profiles/):
+      cpu_config1 : BASELINE configs[0] timed DIRECTLY -- the whole oracle pipeline (CLIP text, 10 x CFG evaluation of
+                    UNet + ControlNet, VAE decode, u8) for 1 image, 1 prompt, 512x512, on the host cores;
+      eager_port  : the same oracle modules on one MI355X through PyTorch-ROCm eager (rocBLAS / MIOpen / SDPA) under bf16
+                    autocast -- the "naive port" a maintainer gets by moving the reference's modules to the GPU -- one image
+                    per call (CFG batch 2), as the reference calls its pipeline."""
+    import numpy as np
+    import torch
+
+    from oracle import pipeline as OP
+    from oracle import sd_models as OM
+    from oracle.canny import generate_canny_array
+    from saspa_aug_amd import config as CFG
+    from saspa_aug_amd import weights as W
+    from saspa_aug_amd.synthetic import negative_prompt_ids, synthetic_image, synthetic_prompt_ids
+    cores = effective_cpus()
+    torch.set_num_threads(cores)
+    cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
+    fam = W.synth_family(cfgs, seed=0)
+    vocab = cfgs["text"]["vocab"]
+    ids = torch.from_numpy(synthetic_prompt_ids(1, seed=1, vocab=vocab))
+    neg = torch.from_numpy(negative_prompt_ids(vocab))
+    ctrl = generate_canny_array(synthetic_image(512, 512, 0), 120, 200)
+    lat = torch.randn((1, 4, 64, 64), generator=torch.Generator().manual_seed(1))
+    out = {}
+    t0 = time.time()
+    OP.sd_controlnet_pipeline(fam, cfgs, ids, neg, ctrl, lat, 10)
+    dt = time.time() - t0
+    f10 = 2135.06e9 * 10 + 2579.2e9
+    out["cpu_config1"] = dict(seconds=round(dt, 2), steps=10, images=1, cores=cores, images_per_s=round(1.0 / dt, 6),
+                              images_per_s_at_50_steps_scaled=round(1.0 / (dt * F_IMG_50 / f10), 6),
+                              cpu_tflops=round(f10 / dt / 1e12, 3),
+                              what="BASELINE configs[0]: torch-CPU fp32 oracle pipeline, 1 image 512x512, 1 prompt, 10 DDIM steps, timed directly")
+    # ---- eager port on the GPU ----
+    sd_u = {k: v.to(dev) for k, v in fam["unet"].items()}
+    sd_c = {k: v.to(dev) for k, v in fam["controlnet"].items()}
+    g = torch.Generator().manual_seed(0)
+    res = {}
+    for bsz in (2, 16):
+        x = torch.randn(bsz, 4, 64, 64, generator=g).to(dev)
+        ctx = torch.randn(bsz, 77, 768, generator=g).to(dev)
+        cond = torch.rand(bsz, 3, 512, 512, generator=g).to(dev)
+
+        def evaluate(t):
+            with torch.no_grad(), torch.device(dev), torch.autocast("cuda", dtype=torch.bfloat16):
+                down, mid = OM.controlnet_forward(sd_c, cfgs["controlnet"], x, t, ctx, cond, 0.75)
+                return OM.unet_forward(sd_u, cfgs["unet"], x, t, ctx, down, mid)
+        try:
+            evaluate(981)
+            evaluate(961)                   # warm (MIOpen find, rocBLAS solution selection)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            n = 5
+            for i in range(n):
+                evaluate(941 - 20 * i)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / n
+            imgs = bsz // 2
+            res[f"cfg_batch_{bsz}"] = dict(ms_per_evaluation=round(dt * 1e3, 2),
+                                           images_per_s_at_50_steps=round(imgs / (dt * 50), 4),
+                                           tflops=round(imgs * 2 * (800.32 + 267.21 + 16.08) * 1e9 / dt / 1e12, 1))
+        except Exception as e:              # a comparator that cannot run must not take the bench line down
+            res[f"cfg_batch_{bsz}"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    out["eager_port"] = dict(what="oracle UNet+ControlNet modules on one MI355X via PyTorch-ROCm eager (rocBLAS / MIOpen / SDPA), "
+                                  "bf16 autocast, un-hoisted (conditioning embedding and text K/V recomputed per step, like "
+                                  "diffusers); images/s counts the 50 evaluations only (VAE / CLIP excluded, i.e. favourable)",
+                             **res)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: start the N rank processes ourselves
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Spawn one child per rank (fresh interpreters; this parent has not imported torch and never touches the GPU -- a
+    GPU-holding process must not exec or fork, see saspa_aug_amd/launcher.py), relay rank 0's stdout (the JSON line), exit
+    non-zero as soon as any rank fails."""
+    import saspa_aug_amd  # noqa: F401   (light: no torch, no HIP library load)
+    from saspa_aug_amd.launcher import launch_ranks as _launch
+    return _launch(n, os.path.abspath(__file__), argv)
+
+
+def newest_traffic_profile():
+    """profiles/*pmc_traffic*.json with the highest (round, version) -- `r2_..._v3` beats `r1_..._v13` beats `r1_..._v7`
+    (a plain sort put `_v7` after `_v13`)."""
+    import glob
+    import re
+    best, best_key = None, None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")):
+        name = os.path.basename(f)
+        r = re.search(r"(?:^|_)r(\d+)_", "_" + name)
+        v = re.search(r"_v(\d+)", name)
+        key = (int(r.group(1)) if r else 0, int(v.group(1)) if v else 0)
+        if best_key is None or key > best_key:
+            best, best_key = f, key
+    return best
+
+
+def dry_run(args):
+    """`--dry`: the N-rank plumbing (rendezvous, per-rank work, the one gather, max-over-ranks timing, the JSON line) on
+    the gloo backend with NO GPU work -- what the CPU tests exercise.  INVALID as a result, and says so."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = args.batch
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    status = []
+    for i in range(args.steps):
+        time.sleep(0.01)                                                  # stands in for one batch on the GPU
+        status.append(torch.full((b,), rank + 1, dtype=torch.int32))
+    st = torch.cat(status)
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty_like(st) for _ in range(world)] if rank == 0 else None
+        dist.gather(st, gathered, dst=0)
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        if gathered is not None:
+            assert [int(g[0]) for g in gathered] == list(range(1, world + 1)), "gather did not deliver every rank's vector"
+        print(json.dumps({"metric": "augmented images/sec (512x512, 50-step DDIM)", "value": round(world * b * args.steps / dt, 4),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                          "config": {"workload": "DRY RUN (gloo, no GPU work) -- plumbing check, not a valid result"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -119,14 +275,42 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--baselines", choices=["sample", "full"], default="sample",
+                    help="full: also time BASELINE configs[0] on the CPU directly and the PyTorch-ROCm eager port (minutes)")
     ap.add_argument("--no-safety-checker", action="store_true",
                     help="A/B only: the reference never disables the SD-1.5 safety checker, so the default step runs it")
     ap.add_argument("--tiny", action="store_true", help="reduced-width family (plumbing check only; INVALID as a result)")
+    ap.add_argument("--dry", action="store_true", help="gloo / no GPU work: checks the multi-rank plumbing only")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as `python bench.py --gpus N` (no torchrun): become the launcher, never touch the GPU here
+        return launch_ranks(args.gpus, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if args.dry:
+        return dry_run(args)
+    return run(args)
+
+
+def run(args):
+    import numpy as np
+    import torch
+
+    import saspa_aug_amd  # noqa: F401
+    from saspa_aug_amd import config as CFG
+    from saspa_aug_amd import ops
+    from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline
+    from saspa_aug_amd.synthetic import negative_prompt_ids, synthetic_image, synthetic_prompt_ids
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: no HIP device {local_rank} visible (bench.py measures the MI355X path; "
+                           "--dry checks the multi-rank plumbing without a GPU)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -190,7 +374,7 @@ def main():
     value = images / dt
     f_img = F_IMG_50 if (s == 50 and res == 512 and not args.tiny) else None
 
-    # ---- roofline of the dominant kernel (HIP events around every launch, one evaluation) ----
+    # ---- roofline of the dominant kernel family (HIP events around every launch, one evaluation) ----
     roof = None
     if rank == 0:
         rec = Recorder()
@@ -203,24 +387,30 @@ def main():
         summ = rec.summary()
         gm = summ["gemm"]
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="gemm_kernel<bf16> (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)",
+        roof = dict(bound="mfma",
+                    kernel="implicit-GEMM conv / linear family: gemm_dma_kernel (LDS-DMA 128x160 / 128x128 tiles), gemm_pp_kernel "
+                           "(8-wave 256x320 / 256x256), gemm_as_kernel (A-stationary short-K linears); v_mfma_f32_16x16x32_bf16",
                     achieved=round(achieved, 1), peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / BF16_PEAK_TFLOPS, 4), traffic=None,
                     launches=gm["launches"], avg_launch_us=round(gm["ms"] * 1e3 / gm["launches"], 2),
                     flops_per_launch_avg=round(gm["flops"] / gm["launches"] / 1e9, 3),
-                    note="achieved = sum of algorithmic FLOPs (2*M*N*K) of every launch of this kernel in a 2-step "
+                    note="achieved = sum of algorithmic FLOPs (2*M*N*K) of every launch of this kernel family in a 2-step "
                          "batch-8 generation / sum of their HIP-event durations")
+        total_ms = sum(d["ms"] for d in summ.values())
+        roof["by_class"] = {
+            k: dict(tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), frac=round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
+                    launches=d["launches"], ms_share=round(d["ms"] / total_ms, 4))
+            for k, d in sorted(rec.summary(by_class=True).items()) if d["ms"] > 0 and d["flops"] > 0}
         # HBM traffic per launch of the same kernel family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
         # tools/pmc_step.py (the same warm + 2-step generation), corrected per MI355X_MICROARCH.md; collected offline
         # (counters cannot be read inside this process) and committed under profiles/ by tools/pmc_traffic_json.py
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic*.json")))
-        if tfiles:
+        tfile = newest_traffic_profile()
+        if tfile:
             try:
-                tj = json.load(open(tfiles[-1]))
+                tj = json.load(open(tfile))
                 roof["traffic"] = round(tj["hbm_bytes_per_launch"])
                 roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE, PMC, avg over the kernel family)"
-                roof["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
+                roof["traffic_source"] = "profiles/" + os.path.basename(tfile)
             except Exception:  # a malformed profile file must not take the bench line down
                 pass
         if "flash_attn" in summ:
@@ -232,8 +422,11 @@ def main():
             roof["pipeline_frac_of_peak"] = round(value / n_gpus * f_img / 1e12 / BF16_PEAK_TFLOPS, 4)
 
     cpu = None
+    extra = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.tiny:
         cpu = cpu_baseline()
+        if args.baselines == "full":
+            extra = baselines_full(dev)
 
     if rank == 0:
         line = {
@@ -246,12 +439,15 @@ def main():
                        "parallelism": f"dp{n_gpus} (image shards, one RCCL gather of the status vector)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if extra is not None:
+            line["baselines_full"] = extra
         if args.tiny:
             line["config"]["workload"] = "TINY plumbing run -- not a valid result"
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

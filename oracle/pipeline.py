@@ -118,10 +118,12 @@ def postprocess(img):
 
 @torch.no_grad()
 def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents, steps,
-                           guidance_scale=7.5, conditioning_scale=0.75, return_latents=False):
+                           guidance_scale=7.5, conditioning_scale=0.75, return_latents=False, trace=None):
     """weights: dict(unet=, controlnet=, vae=, text=) of diffusers-named state dicts.
     ids_*: int64 [1,77].  control_u8: u8 [H,W,3].  latents: fp32 [1,4,H/8,W/8] noise.
-    Returns u8 [1,H,W,3] (and the final latents / decoded float image if asked)."""
+    Returns u8 [1,H,W,3] (and the final latents / decoded float image if asked).  `trace` (a list) receives one
+    dict(t, x, eps2, ctx) per step: the latents going INTO the evaluation and the two CFG halves coming out of it
+    (teacher-forced per-evaluation checks of the bf16 path)."""
     ctx = M.clip_text_forward(weights["text"], cfgs["text"], torch.cat([ids_neg, ids_pos], 0))
     cond = prepare_control(control_u8)
     cond2 = torch.cat([cond, cond], 0)
@@ -132,6 +134,8 @@ def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents,
         down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x2, int(t), ctx, cond2,
                                          conditioning_scale)
         eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
+        if trace is not None:
+            trace.append(dict(t=int(t), x=x.clone(), eps2=eps2.clone(), ctx=ctx))
         eps_u, eps_c = eps2.chunk(2)
         eps = eps_u + guidance_scale * (eps_c - eps_u)
         x = sch.step(eps, t, x)

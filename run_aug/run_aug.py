@@ -3,7 +3,8 @@
 the reference's run_aug/run_aug.py:513-556) and run
 
     python run_aug/run_aug.py                                   # one MI355X
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_aug/run_aug.py   # 8 MI355X
+    SASPA_GPUS=8 python run_aug/run_aug.py                      # 8 MI355X: this script starts the 8 ranks itself
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_aug/run_aug.py   # same, via torchrun
 
 Environment overlays (optional): SASPA_DATASET, SASPA_WEIGHTS_DIR, SASPA_PROMPTS_FILE,
 SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION, SASPA_BASE_MODEL (sd_v1.5 | blip_diffusion | sd_xl-turbo)."""
@@ -14,6 +15,12 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 import saspa_aug_amd  # noqa: E402,F401
+
+if __name__ == "__main__" and int(os.environ.get("SASPA_GPUS", "1")) > 1 and "WORLD_SIZE" not in os.environ:
+    # become the launcher BEFORE torch is imported: the parent never touches the GPU (saspa_aug_amd/launcher.py)
+    from saspa_aug_amd.launcher import launch_ranks  # noqa: E402
+    sys.exit(launch_ranks(int(os.environ["SASPA_GPUS"]), __file__, sys.argv[1:]))
+
 from saspa_aug_amd import run_aug as R  # noqa: E402
 
 if __name__ == "__main__":

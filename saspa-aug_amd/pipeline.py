@@ -202,6 +202,12 @@ class StableDiffusionControlNetPipeline:
         else:
             raise TypeError(f"unsupported pipeline dtype {dtype}")
         self.device, self.dtype, self.noise_dtype = device, cdt, ndt
+        # the kernels launch on the CURRENT HIP device / torch's current stream of it: make the pipeline's device current
+        # (the reference's idiom is editing DEVICE = "cuda:1"; without this tensors would live on GPU 1, launches on GPU 0)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)
+        self.device = device
         sd, cf = self._state_dicts, self.cfgs
         self.unet = models.UNet(sd["unet"], cf["unet"], device, cdt)
         self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt)
@@ -230,6 +236,8 @@ class StableDiffusionControlNetPipeline:
     def _need_device(self):
         if self.unet is None:
             raise RuntimeError("pipeline not placed on a device: call .to('cuda:0', dtype) first")
+        if torch.cuda.current_device() != self.device.index:       # another pipeline / caller switched devices since
+            torch.cuda.set_device(self.device)
 
     def encode_prompts(self, ids):
         """ids: int array/tensor [n,77] -> [n,77,ctx_dim] device tensor (CLIP text tower)."""

@@ -322,8 +322,12 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
     utils.set_seed(SEED) (and dataset construction), like the reference's loop."""
     if image_size_fn is None:
         def image_size_fn(path):
+            # the size AFTER the EXIF transpose load_source applies (diffusers.utils.load_image does the same): orientations
+            # 5-8 swap the sides, and the plan's bucket / noise shape must be the loaded image's
             with Image.open(path) as im:
                 w, h = im.size
+                if im.getexif().get(0x0112, 1) in (5, 6, 7, 8):
+                    w, h = h, w
             th, tw, _ = utils.resize_target_size(h, w, s.RESOLUTION)
             return th, tw
     if s.DEBUG:
@@ -528,8 +532,9 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
             images, controls = batch_generator.finish(handle)
         except RuntimeError as e:
             failed(batch, e)
-            return
+            return False
         emit(batch, images, controls, sources, subjects)
+        return True
 
     def emit(batch, images, controls, sources, subjects):
         for k, it in enumerate(batch):
@@ -569,9 +574,17 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
         if pipelined:
             if inflight is not None:
                 t2 = _time.time()
-                drain(inflight)
+                ok = drain(inflight)
                 if prof:
                     print(f"[loop] batch {bi}: drain of the previous batch {_time.time() - t2:.3f} s", flush=True)
+                if not ok and num_errors > 20:       # asynchronous failures surface here: same abort rule (:497-500)
+                    logging.info("Too many errors, stopping generation on this rank")
+                    try:
+                        batch_generator.finish(handle)
+                    except RuntimeError as e:
+                        failed(batch, e)
+                    inflight = None
+                    break
             inflight = (batch, handle, sources, subjects)
         else:
             emit(batch, images, controls, sources, subjects)

@@ -11,6 +11,7 @@ checkpoint, which is not available offline, so:
 import json
 import os
 import re
+import unicodedata
 import zlib
 from functools import lru_cache
 
@@ -53,7 +54,11 @@ class CLIPBPETokenizer:
         self.byte_enc = _bytes_to_unicode()
         self.max_len = max_len
         self.bos, self.eos = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
-        self.pat = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[a-z]+|[0-9]|[^\sa-z0-9]+")
+        # CLIP's pre-tokenisation pattern (openai/CLIP simple_tokenizer.py, transformers CLIPTokenizer): unicode letter /
+        # number classes need the `regex` module -- `[a-z]+` would split accented sub-class names into punctuation tokens
+        import regex
+        self.pat = regex.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                 regex.IGNORECASE)
         self.cache = {}
 
     def _bpe(self, token):
@@ -80,11 +85,16 @@ class CLIPBPETokenizer:
 
     def __call__(self, text, max_len=None):
         max_len = max_len or self.max_len
-        text = re.sub(r"\s+", " ", (text or "")).strip().lower()
+        # CLIPTokenizer's normaliser (transformers: NFC, whitespace runs -> one space, lower-case; accents kept).  The slow
+        # tokenizer's optional ftfy.fix_text pass (mojibake / HTML-entity repair) is NOT reproduced: it is the identity on
+        # the ASCII prompts of the reference's prompt files.
+        text = unicodedata.normalize("NFC", text or "")
+        text = re.sub(r"\s+", " ", text).strip().lower()
+        unk = self.encoder.get("<|endoftext|>")
         ids = []
-        for tok in re.findall(self.pat, text):
+        for tok in self.pat.findall(text):
             tok = "".join(self.byte_enc[b] for b in tok.encode("utf-8"))
-            ids += [self.encoder[p] for p in self._bpe(tok)]
+            ids += [self.encoder.get(p, unk) for p in self._bpe(tok)]
         ids = [self.bos] + ids[: max_len - 2] + [self.eos]
         ids += [self.eos] * (max_len - len(ids))
         return np.asarray(ids, np.int64)[None]

@@ -18,7 +18,6 @@ import json
 import logging
 import os
 import random
-import sys
 from pathlib import Path
 
 import numpy as np
@@ -130,24 +129,26 @@ def get_aug_json_path(augmented_image_folder_path, lpips_min=None, lpips_max=Non
 
 
 def check_folder_of_images_with_pil(folder, max_delete=20, substrings_to_exclude=None):
-    substrings_to_exclude = substrings_to_exclude or []
-    num_deleted = 0
-    file_names = [f for f in os.listdir(folder) if not any(s in f for s in substrings_to_exclude)]
-    for image_name in file_names:
-        image_path = Path(folder) / image_name
+    """Integrity sweep over the generated files before they are listed in the JSON (interface of
+    all_utils/utils.py:681-703): every file whose name carries none of `substrings_to_exclude` must pass PIL's
+    structural check; broken ones (a writer killed mid-file) are removed so training never opens them.  Stops
+    after `max_delete` removals -- more than that means the run itself is broken, not a few files."""
+    skip = tuple(substrings_to_exclude or ())
+    removed = 0
+    with os.scandir(folder) as entries:
+        candidates = sorted(e.path for e in entries if e.is_file() and not any(t in e.name for t in skip))
+    for path in candidates:
+        if removed >= max_delete:
+            break
         try:
-            img = Image.open(image_path)
-            img.verify()
-        except KeyboardInterrupt:
-            sys.exit(0)
-        except Exception:
-            logging.info(f"image {image_path} is corrupted, deleting")
-            os.remove(image_path)
-            num_deleted += 1
-            if num_deleted >= max_delete:
-                break
-    logging.info(f"Finished checking folder {folder} with PIL, deleted {num_deleted} images")
-    return num_deleted
+            with Image.open(path) as im:
+                im.verify()
+        except Exception as err:            # PIL raises several unrelated types for truncated / non-image files
+            logging.info(f"image {path} is corrupted ({type(err).__name__}), deleting")
+            os.remove(path)
+            removed += 1
+    logging.info(f"Finished checking folder {folder} with PIL, deleted {removed} images")
+    return removed
 
 
 def match_augmented_images(original_images_paths, all_file_names, augmented_image_folder_path):
@@ -209,28 +210,39 @@ def create_json_of_image_name_to_augmented_images_paths(dataset, augmented_image
     return json_path
 
 
-def init_logging(logdir=None, logfile=None, return_logger=False):
-    assert logdir or logfile, "logdir or logfile must be provided"
-    date_uid = str(datetime.datetime.now().strftime("%Y_%m%d_%H%M_%S"))
+def _log_file_for(logdir, logfile, stamp):
     if logdir:
         os.makedirs(logdir, exist_ok=True)
-        log_file = os.path.join(logdir, f"{date_uid}_log.log")
-    else:
-        parent_folder = Path(logfile).parent
-        parent_folder.mkdir(parents=True, exist_ok=True)
-        log_file = str(parent_folder / f"{Path(logfile).stem}_{date_uid}{Path(logfile).suffix}")
-    logging.basicConfig(format="%(asctime)s %(levelname)s %(message)s", level=logging.INFO)
-    fh = logging.FileHandler(log_file, mode="w")
-    fh.setFormatter(logging.Formatter("%(asctime)s %(levelname)s %(message)s"))
-    logging.getLogger().addHandler(fh)
-    return logging.getLogger() if return_logger else logdir
+        return os.path.join(logdir, f"{stamp}_log.log")
+    target = Path(logfile)
+    target.parent.mkdir(parents=True, exist_ok=True)
+    return str(target.with_name(f"{target.stem}_{stamp}{target.suffix}"))
+
+
+def init_logging(logdir=None, logfile=None, return_logger=False):
+    """Root logger to the console and to a time-stamped file: `{logdir}/{stamp}_log.log`, or `logfile` with the stamp
+    inserted before its suffix (interface of all_utils/utils.py:593-612; called once per process, so the file handler is
+    replaced rather than stacked when a second stage -- the JSON writer -- logs next to the first)."""
+    if not (logdir or logfile):
+        raise AssertionError("logdir or logfile must be provided")
+    stamp = datetime.datetime.now().strftime("%Y_%m%d_%H%M_%S")
+    fmt = "%(asctime)s %(levelname)s %(message)s"
+    root = logging.getLogger()
+    logging.basicConfig(format=fmt, level=logging.INFO)
+    root.setLevel(logging.INFO)
+    for h in [h for h in root.handlers if getattr(h, "_saspa_file", False)]:
+        root.removeHandler(h)
+        h.close()
+    handler = logging.FileHandler(_log_file_for(logdir, logfile, stamp), mode="w")
+    handler.setFormatter(logging.Formatter(fmt))
+    handler._saspa_file = True
+    root.addHandler(handler)
+    return root if return_logger else logdir
 
 
 def load_data(file_path):
-    """'<image_id> <info...>' lines -> dict (all_utils/utils.py:615-621)."""
-    data = {}
+    """FGVC-Aircraft annotation file -> {image id: rest of the line} ("1025794 Boeing" / "0734043 707-320";
+    the value may itself contain spaces).  Interface of all_utils/utils.py:615-621."""
     with open(file_path, "r") as f:
-        for line in f:
-            image_id, info = line.strip().split(" ", 1)
-            data[image_id] = info
-    return data
+        pairs = (line.rstrip("\n").strip().partition(" ") for line in f)
+        return {image_id: info for image_id, _, info in pairs if image_id}

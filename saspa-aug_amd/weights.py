@@ -8,6 +8,7 @@ architecture-exact tensors under the SAME key names (a real `*.safetensors` load
 biases, norm gains around 1 -- keeps activations O(1) through 50 steps and avoids
 all-zero MFMA operands."""
 import math
+import re
 
 import torch
 
@@ -273,10 +274,33 @@ def synth_family(cfgs, seed=0):
     return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
 
 
+_LEGACY_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def remap_legacy_attention_keys(sd):
+    """Checkpoints saved before diffusers 0.7 (runwayml/stable-diffusion-v1-5's `vae/`, `sd-vae-ft-mse`) carry the old
+    `AttentionBlock` names `<attn>.query|key|value|proj_attn.{weight,bias}`; diffusers renames them at load time
+    (`_convert_deprecated_attention_blocks`) to `to_q|to_k|to_v|to_out.0`.  Same remap here; 1x1-conv shaped weights
+    ([C, C, 1, 1], the even older conv form) are squeezed to the Linear shape.  Keys already in the new form pass."""
+    out = {}
+    for k, v in sd.items():
+        m = re.match(r"^(.*\.attentions\.\d+)\.(query|key|value|proj_attn)\.(weight|bias)$", k)
+        if m:
+            k = f"{m.group(1)}.{_LEGACY_ATTN_KEYS[m.group(2)]}.{m.group(3)}"
+            if m.group(3) == "weight" and v.dim() == 4 and v.shape[2:] == (1, 1):
+                v = v[:, :, 0, 0]
+        elif re.match(r"^.*\.attentions\.\d+\.to_(q|k|v|out\.0)\.weight$", k) and v.dim() == 4 and v.shape[2:] == (1, 1):
+            v = v[:, :, 0, 0]
+        if k in out:
+            raise KeyError(f"checkpoint holds both the legacy and the current name of {k}")
+        out[k] = v
+    return out
+
+
 def load_safetensors(path):
-    """Read a diffusers `*.safetensors` checkpoint into an fp32 state dict."""
+    """Read a diffusers `*.safetensors` checkpoint into an fp32 state dict (legacy attention key names remapped)."""
     from safetensors.torch import load_file
-    return {k: v.float() for k, v in load_file(path).items()}
+    return remap_legacy_attention_keys({k: v.float() for k, v in load_file(path).items()})
 
 
 # --------------------------------------------------------------------------------------

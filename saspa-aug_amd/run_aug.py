@@ -298,9 +298,13 @@ def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strengt
 # ------------------------------------------------------------------------------------------
 # planning pass: replay of the reference's host RNG (run_aug/run_aug.py:357-434)
 # ------------------------------------------------------------------------------------------
-def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image_classes_dict):
-    """Artistic / camera suffixes and sub-class injection, consuming the python / numpy RNG
-    streams exactly like run_aug/run_aug.py:391-427."""
+def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image_classes_dict, ds_utils=None):
+    """Car-part prefix, artistic / camera suffixes and sub-class injection, consuming the python / numpy RNG streams
+    exactly like run_aug/run_aug.py:386-427 (per dataset: planes / cars look the class up by image stem, dtd / cub /
+    compcars-parts by image path)."""
+    if s.DATASET == "compcars-parts":                         # :387-390 the photographed part goes in front
+        part = source_image_path.split("/")[-2]
+        prompt = f"{ds_utils.get_basic_prompt(part=part)} {prompt}"
     if s.USE_ARTISTIC_PROMPTS and ((i % 2 == 0 and s.ARTISTIC_PROMPTS_PROB == 0.5) or
                                    (random.random() < s.ARTISTIC_PROMPTS_PROB and s.ARTISTIC_PROMPTS_PROB != 0.5)):
         prompt = f"{prompt}, {np.random.choice(ARTISTIC_PROMPTS)}"
@@ -311,13 +315,37 @@ def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image
             prompt = prompt.replace("airplane", f"{image_classes_dict[image_stem]} airplane")
         elif s.DATASET == "cars":
             prompt = prompt.replace("car", f"{image_classes_dict[image_stem]} car")
+        elif s.DATASET == "dtd":
+            prompt = f"{prompt} with a {image_classes_dict[source_image_path]} texture"
+        elif s.DATASET in ("compcars", "compcars-parts"):
+            prompt = prompt.replace("car", f"{image_classes_dict[source_image_path]} car")
+        elif s.DATASET == "cub":
+            prompt = prompt.replace("bird", f"{image_classes_dict[source_image_path]} bird")
         else:
             raise NotImplementedError(s.DATASET)
     return prompt
 
 
+def default_prompts_file(s: Settings):
+    """The prompt source the reference's config block selects per dataset (run_aug/run_aug.py:589-666) for
+    PROMPT_TYPE "gpt-meta_class" (100 GPT-written prompts per meta class, shipped as data next to this module) or
+    "captions" (per-image BLIP captions: DTD only)."""
+    here = Path(__file__).parent / "prompts_engineering"
+    if s.PROMPT_TYPE == "captions":
+        if s.DATASET != "dtd":
+            raise NotImplementedError(f"no caption file ships for {s.DATASET} (the reference has dtd_captions.json only)")
+        return str(here / "captions" / "dtd_captions.json")
+    if s.PROMPT_TYPE != "gpt-meta_class":
+        raise NotImplementedError(f"PROMPT_TYPE {s.PROMPT_TYPE}: txt2sentence / ALIA prompt sets are baseline branches")
+    name = {"planes": "planes", "planes_biased": "planes", "synthetic": "planes", "cars": "cars", "compcars-parts": "cars",
+            "cub": "cub"}.get(s.DATASET)
+    if name is None:
+        raise NotImplementedError(f"no gpt-meta_class prompt file for {s.DATASET}")
+    return str(here / "gpt_prompts" / f"{name}-100-gpt_v1.txt")
+
+
 def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None,
-              same_class_fn=None):
+              same_class_fn=None, ds_utils=None, captions=None):
     """Returns the work items in the reference's loop order.  Must be called right after
     utils.set_seed(SEED) (and dataset construction), like the reference's loop."""
     if image_size_fn is None:
@@ -335,15 +363,18 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
             original_images_paths = [p for p in original_images_paths if any(x in p for x in s.SPECIFIC_FILE_STRs)]
         else:
             original_images_paths = original_images_paths[:4]
-    prompts = [p[:-1] if p and p[-1] == "." else p for p in prompts]        # :380 (idempotent)
+    prompts = [p[:-1] if p and p[-1] == "." else p for p in (prompts or [])]        # :380 (idempotent)
     items = []
     noise_cursor = 0
     for index, source_image_path in enumerate(original_images_paths):
         image_stem = Path(source_image_path).stem
         th, tw = image_size_fn(source_image_path)
+        if s.PROMPT_TYPE == "captions":                                      # :361-363 the image's own BLIP caption, N times
+            cap = captions[source_image_path]["caption"][:MAX_PROMPT_LENGTH]
+            prompts = [cap[:-1] if cap and cap[-1] == "." else cap] * s.NUM_PER_IMAGE
         sampled = np.random.choice(prompts, s.NUM_PER_IMAGE)                 # :382
         for i, prompt in enumerate(sampled):
-            prompt = decorate_prompt(s, str(prompt), i, image_stem, source_image_path, image_classes_dict)
+            prompt = decorate_prompt(s, str(prompt), i, image_stem, source_image_path, image_classes_dict, ds_utils)
             output_path = Path(output_folder) / f"{image_stem[:MAX_FILENAME_LENGTH]}_prompt_{prompt.replace('/', '-')}_{i}.png"
             it = WorkItem(len(items), index, source_image_path, image_stem, i, prompt, str(output_path), th, tw)
             if output_path.exists():
@@ -468,7 +499,10 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
     utils.set_seed(s.SEED)
     if ds_utils is None:
         ds_utils = dataset_utils.DS_UTILS_DICT[s.DATASET](**s.DATASET_KWARGS)
-    prompts_file = s.PROMPTS_FILE or str(Path("prompts_engineering/gpt_prompts") / f"{'planes' if s.DATASET != 'cars' else 'cars'}-100-gpt_v1.txt")
+    if s.DATASET == "dtd" and s.PROMPT_TYPE != "captions":        # run_aug/run_aug.py:611-616: DTD runs on captions only
+        logging.info("DTD is generated from per-image captions: PROMPT_TYPE -> captions")
+        s.PROMPT_TYPE = "captions"
+    prompts_file = s.PROMPTS_FILE or default_prompts_file(s)
     output_folder = output_folder_for(s, ds_utils.root_path)
     if rank == 0:
         Path(output_folder).mkdir(parents=True, exist_ok=True)
@@ -476,16 +510,25 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
         dist.barrier()
     if rank == 0:
         utils.init_logging(str(Path(output_folder).parent))
-    image_classes_dict = ds_utils.get_image_stem_to_class_str_dict()
-    prompts = read_prompts(prompts_file)
-    logging.info(f"Read {len(prompts)} prompts from {prompts_file}")
+    image_classes_dict = ds_utils.get_image_stem_to_class_str_dict()     # path-keyed for dtd / cub / compcars-parts (:700)
+    captions = None
+    if s.PROMPT_TYPE == "captions":
+        import json as _json
+        with open(prompts_file, "r") as f:
+            captions = _json.load(f)
+        prompts = None
+        logging.info(f"Read {len(captions)} captions from {prompts_file}")
+    else:
+        prompts = read_prompts(prompts_file)
+        logging.info(f"Read {len(prompts)} prompts from {prompts_file}")
     aug_json_path = utils.get_aug_json_path(output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
                                             model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING)
     logging.info(f"Augmented json path will be at: \n{aug_json_path}")
 
     blip = "blip_diffusion" in s.BASE_MODEL
     items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict,
-                      same_class_fn=ds_utils.get_image_path_with_same_class if blip else None)
+                      same_class_fn=ds_utils.get_image_path_with_same_class if blip else None, ds_utils=ds_utils,
+                      captions=captions)
     mine = shard_items(items, world)[rank]
     logging.info(f"rank {rank}/{world}: {len(mine)} of {len(items)} work items ({sum(i.skip for i in items)} already exist)")
 

@@ -428,8 +428,13 @@ class ControlNet(_Net):
     def forward(self, sample, step, cond_emb, scale, unet_skips=None, unet_mid=None):
         """Returns ([12 residuals], mid residual), each scale*(zero_conv(feature)) and, when the
         UNet encoder outputs are given, already summed with them (fused epilogue)."""
-        p = self.p
         mid, feats = self.encode(sample, step, conv_in_residual=cond_emb)
+        return self.zero_convs(mid, feats, scale, unet_skips, unet_mid)
+
+    def zero_convs(self, mid, feats, scale, unet_skips=None, unet_mid=None):
+        """The 12 + 1 zero convolutions on the encoder features (x conditioning scale, + the UNet's own skips / mid when
+        given): the point where the ControlNet branch joins the UNet."""
+        p = self.p
         outs = []
         for i, f in enumerate(feats):
             r = None if unet_skips is None else unet_skips[i]

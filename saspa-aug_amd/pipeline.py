@@ -40,6 +40,12 @@ def graphs_enabled():
     return os.environ.get("SASPA_GRAPH", "1") != "0" and ops._RECORDER is None
 
 
+def fork_enabled():
+    """Two-branch sampling step (UNet encoder || ControlNet encoder inside the captured graph).  SASPA_FORK=0 captures
+    the single-stream order."""
+    return os.environ.get("SASPA_FORK", "1") != "0"
+
+
 class _StepGraph:
     """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM or PLMS update,
     ~1 500 kernel nodes -- replayed once per network evaluation.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
@@ -66,6 +72,7 @@ class _StepGraph:
         self.nets = (pipe.unet, pipe.controlnet)
         self.tables, self.curs, self.ctx_kv = [], [], []
         self.graph = None
+        self.side = None                  # second capture stream of the forked step (fork_enabled)
 
     def _bind(self):
         """Point the networks at this graph's static state."""
@@ -109,8 +116,22 @@ class _StepGraph:
         pipe, x = self.pipe, self.x
         for net, tab, cur in zip(self.nets, self.tables, self.curs):
             ops.gather_row(tab, self.idx, cur)
-        mid, skips = pipe.unet.encode(x, None)
-        skips2, mid2 = pipe.controlnet.forward(x, None, self.cemb, self.cscale, skips, mid)
+        if fork_enabled():
+            # the UNet encoder and the ControlNet encoder are independent until the zero convs add the two: two
+            # branches of the captured graph.  Same kernels on the same inputs -> bit-identical to the single-stream order; what
+            # changes is that one branch's launch gaps / tile tails / small deep-level kernels are filled by the other's work.
+            main = torch.cuda.current_stream()
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=x.device)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                cmid, cfeats = pipe.controlnet.encode(x, None, conv_in_residual=self.cemb)
+            mid, skips = pipe.unet.encode(x, None)
+            main.wait_stream(self.side)
+            skips2, mid2 = pipe.controlnet.zero_convs(cmid, cfeats, self.cscale, skips, mid)
+        else:
+            mid, skips = pipe.unet.encode(x, None)
+            skips2, mid2 = pipe.controlnet.forward(x, None, self.cemb, self.cscale, skips, mid)
         pipe.unet.decode(mid2, skips2, None, out=self.eps)
         nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
         nc, hw = pipe.cfgs["unet"]["out_channels"], x.shape[1] * x.shape[2]

@@ -44,6 +44,9 @@ extern "C" {
  * output tile of BN columns (BN = 160 if N % 160 == 0 else 128; N % BN == 0 required):
  * tile t holds features [t*BN/2, (t+1)*BN/2) -- their value rows first, then their gate rows. */
 #define SASPA_ACT_GEGLU 3
+/* filter stage (CLIP-RN50 / WSDAN_CAL ResNet convs with the BatchNorm folded into weights + bias): */
+#define SASPA_ACT_RELU 5     /* out = relu(alpha*(acc + bias + rowvec)) + residual */
+#define SASPA_ACT_ADD_RELU 6 /* out = relu(alpha*(acc + bias + rowvec) + residual): Bottleneck "out += identity; relu" */
 
 #define SASPA_GEMM_AUTO 0
 #define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
@@ -167,7 +170,7 @@ int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long lo
 /* ---- elementwise ----------------------------------------------------------*/
 /* GEGLU: y[m][f] = x[m][f] * gelu_erf(x[m][F+f])   (diffusers GEGLU) */
 int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int F, void* stream);
-/* act: 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) (CLIP MLP), 4 erf-GELU (BERT / Q-Former FFN); in/out [rows][C] */
+/* act: 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) (CLIP MLP), 4 erf-GELU (BERT / Q-Former FFN), 5 ReLU; in/out [rows][C] */
 int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
                      void* stream);
 /* CLIP embeddings: out[i][:] = tok[ids[i]][:] + pos[i % npos][:] */
@@ -260,6 +263,17 @@ int saspa_u8_to_act_norm(int dtype, const uint8_t* src, void* dst, long long npi
 int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, int nimg, const double* special_w,
                         int n_special, const double* concept_w, int n_concepts, double threshold, uint8_t* images,
                         long long bytes_per_image, int* flags, void* stream);
+
+/* ---- filter stage (all_utils/utils.py:306-323, :357-375) ----------------------------------------------
+ * 2-D pooling over channels-last activations [batch][hin][win][C] -> [batch][hout][wout][C], hout = (hin + 2*pad - k) /
+ * stride + 1: mode 0 = max (nn.MaxPool2d(3, 2, 1) of the ResNet stem: padding never wins), mode 1 = average over the k*k
+ * window (nn.AvgPool2d(k): CLIP's anti-aliased strides, the attention pool's mean token; pad must be 0).  C % 8 == 0. */
+int saspa_pool2d(int dtype, int mode, const void* x, int ldx, void* y, int ldy, int batch, int hin, int win, int C, int k,
+                 int stride, int pad, void* stream);
+/* Bilinear-attention-pooling tail of WSDAN_CAL (fgvc/models/cal.py:73-77): per row of [rows][C],
+ * y = sign(x) * sqrt(|x| + eps); out = scale * y / max(||y||_2, 1e-12).  fp32 in / out. */
+int saspa_signsqrt_l2norm(const float* x, long long ldx, float* y, long long ldy, int rows, long long C, float eps,
+                          float scale, void* stream);
 
 /* library self-description */
 int saspa_abi_version(void);

@@ -74,6 +74,8 @@ SYMBOLS = {
     "saspa_resample_u8": (_I, [_P, _P, _LL, _I, _I, _I, _P, _P, _I, _P]),
     "saspa_u8_to_act_norm": (_I, [_I, _P, _P, _LL, _F, _F, _F, _F, _F, _F, _P]),
     "saspa_safety_decide": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, C.c_double, _P, _LL, _P, _P]),
+    "saspa_pool2d": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "saspa_signsqrt_l2norm": (_I, [_P, _LL, _P, _LL, _I, _LL, _F, _F, _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

@@ -57,6 +57,25 @@ BLIP_IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
 BLIP_DIFFUSION = dict({k: v for k, v in SD15.items() if k != "safety"}, qformer=BLIP2_QFORMER, ctx_begin_pos=2)
 
 
+# ---- filter stage (all_utils/utils.py:252-255, :306-323, :357-375) ----
+# OpenAI CLIP "RN50" (clip.load('RN50')): ModifiedResNet (3, 4, 6, 3) width 64 -> 2048 channels at 7x7, attention pool with
+# 32 heads -> 1024-d embedding; text tower 12 layers x 512 wide x 8 heads, context 77.  Recalled from the public model.py.
+CLIP_RN50 = dict(image_size=224, layers=(3, 4, 6, 3), width=64, heads=32, embed_dim=1024, vocab=49408, text_width=512,
+                 text_heads=8, text_layers=12, context=77)
+# the baseline classifier: WSDAN_CAL on ResNet-101 features (fgvc/models/cal.py:131-166; resnet50 is the fallback of
+# BaseUtils.load_baseline_model, all_utils/dataset_utils.py:101-109), 32 attention maps, 224 x 224 crops
+WSDAN_CAL_R101 = dict(image_size=224, layers=(3, 4, 23, 3), width=64, attentions=32)
+WSDAN_CAL_R50 = dict(image_size=224, layers=(3, 4, 6, 3), width=64, attentions=32)
+
+
+def tiny_filters(num_classes=12):
+    """Reduced-width filter models with the same topology (tests)."""
+    rn = dict(image_size=64, layers=(1, 1, 1, 1), width=16, heads=4, embed_dim=32, vocab=512, text_width=32, text_heads=2,
+              text_layers=2, context=77)
+    cal = dict(image_size=64, layers=(1, 1, 2, 1), width=16, attentions=8, num_classes=num_classes)
+    return dict(clip_rn50=rn, cal=cal)
+
+
 def tiny_xl(width=32, ctx1=32, ctx2=64, groups=8, vae_width=16):
     """Reduced-width SDXL family with the same topology: 3 levels, no attention at level 0, transformer depths
     (2, 3), linear projections, head dim 16, two text towers (ctx1 | ctx2), text_time addition embedding."""

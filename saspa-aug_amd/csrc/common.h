@@ -92,6 +92,11 @@ template <> struct Elem<float> {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// activation applied BEFORE the residual add (SiLU, ReLU) / AFTER it (ReLU of ResNet bottlenecks); see saspa_hip.h
+__device__ __forceinline__ float act_pre(int act, float x) {
+  return act == SASPA_ACT_SILU ? silu_f(x) : (act == SASPA_ACT_RELU ? fmaxf(x, 0.0f) : x);
+}
+__device__ __forceinline__ float act_post(int act, float x) { return act == SASPA_ACT_ADD_RELU ? fmaxf(x, 0.0f) : x; }
 
 // erf for the bf16 GEGLU epilogue: Abramowitz-Stegun 7.1.26, |error| < 1.5e-7 (far below the
 // bf16 output rounding 2^-9), one v_exp + one v_rcp + 6 FMAs instead of libm's ~50-instruction erff.

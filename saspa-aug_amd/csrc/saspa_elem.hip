@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void activation_kernel(int act, const T* x, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (act == 1) a[j] = silu_f(a[j]);
+      else if (act == 5) a[j] = fmaxf(a[j], 0.0f);
       else if (act == 4) a[j] = 0.5f * a[j] * (1.0f + erff(a[j] * 0.70710678118654752440f));   // exact (erf) GELU: BERT / Q-Former FFN
       else a[j] = a[j] / (1.0f + expf(-1.702f * a[j]));
     }
@@ -238,7 +239,7 @@ extern "C" int saspa_geglu(int dtype, const void* x, int ldx, void* y, int ldy, 
 
 extern "C" int saspa_activation(int dtype, int act, const void* x, int ldx, void* y, int ldy, long long rows, int C,
                                 void* stream) {
-  if (!x || !y || rows <= 0 || C <= 0 || (act != 1 && act != 2 && act != 4)) return SASPA_EINVAL;
+  if (!x || !y || rows <= 0 || C <= 0 || (act != 1 && act != 2 && act != 4 && act != 5)) return SASPA_EINVAL;
   if (C % 8 || ldx % 8 || ldy % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SASPA_BF16)
@@ -446,5 +447,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 8; }
+extern "C" int saspa_abi_version(void) { return 9; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

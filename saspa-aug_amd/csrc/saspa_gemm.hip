@@ -146,18 +146,25 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
         const int m = cbm * BM + row, n = cbn * BN + ch * 8;
         if (m >= p.M || n >= p.N) continue;
         u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
-        if (res || p.act == SASPA_ACT_SILU) {
+        if (res || p.act != SASPA_ACT_NONE) {
           float a[8];
           unpack8(__builtin_bit_cast(uint4, c4), a);
           if (p.act == SASPA_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
+          } else if (p.act == SASPA_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
           }
           if (res) {
             float b[8];
             Elem<bf16_t>::load_chunk(reinterpret_cast<const bf16_t*>(res) + (long long)m * p.ldr + n, b);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] += b[e];
+          }
+          if (p.act == SASPA_ACT_ADD_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
           }
           c4 = __builtin_bit_cast(u32x4, pack8(a));
         }
@@ -201,26 +208,24 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
           v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= p.alpha;
-          if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = act_pre(p.act, v[r] * p.alpha);
         if (res) {
           float rr[4];
           Elem<T>::load4(res + (long long)m * p.ldr + n, rr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rr[r];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_post(p.act, v[r]);
         Elem<T>::store4(out + (long long)m * p.ldo + n, v);
       } else {
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
           float x = v[r];
           if (p.bias) x += p.bias[n + r];
           if (rv) x += rv[n + r];
-          x *= p.alpha;
-          if (p.act == SASPA_ACT_SILU) x = silu_f(x);
+          x = act_pre(p.act, x * p.alpha);
           if (res) x += Elem<T>::load1(res + (long long)m * p.ldr + n + r);
-          Elem<T>::store1(out + (long long)m * p.ldo + n + r, x);
+          Elem<T>::store1(out + (long long)m * p.ldo + n + r, act_post(p.act, x));
         }
       }
     }
@@ -807,16 +812,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SaspaGemmParam
       v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] *= p.alpha;
-      if (p.act == SASPA_ACT_SILU) v[r] = silu_f(v[r]);
-    }
+    for (int r = 0; r < 4; ++r) v[r] = act_pre(p.act, v[r] * p.alpha);
     if (res) {
       float rr[4];
       Elem<T>::load4(res + (long long)m * p.ldr + n, rr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += rr[r];
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = act_post(p.act, v[r]);
     Elem<T>::store4(out + (long long)m * p.ldo + n, v);
   }
 }
@@ -993,7 +997,11 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     const long long a1b = p.c1 > 0 ? (long long)p.batch * p.hin * p.win * p.lda1 * esz : 0;
     const long long wb = (long long)p.N * p.ldw * esz;
     if (a0b >= (1ll << 31) || a1b >= (1ll << 31) || wb >= (1ll << 31)) return SASPA_ERANGE;
-    if (p.kh * p.kw > 31) return SASPA_ERANGE;
+    // the tap-validity bitmask of the fast loaders (a K-tile inside one tap) holds 31 taps; larger windows (the 7x7 stem of
+    // the filter stage's ResNet, 3 -> 8 padded channels) run on the generic per-lane loader, which has no mask
+    const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
+    const bool fastpath = ((p.c0 + p.c1) % bk) == 0 && (p.c1 == 0 || (p.c0 % bk) == 0);
+    if (p.kh * p.kw > 31 && fastpath) return SASPA_ERANGE;
   }
   if (p.ksplit < 0 || p.ksplit > 64) return SASPA_ERANGE;
   if (p.korder != SASPA_KORDER_TAP && p.korder != SASPA_KORDER_CHUNK) return SASPA_EINVAL;
@@ -1007,7 +1015,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     const int bn = (p.N % 160) == 0 ? 160 : 128;
     if (p.dtype != SASPA_BF16 || p.N % bn || p.residual || p.ldo % 8 || p.ldo < p.N / 2) return SASPA_ERANGE;
     p.ksplit = 1;
-  } else if (p.act != SASPA_ACT_NONE && p.act != SASPA_ACT_SILU) {
+  } else if (p.act != SASPA_ACT_NONE && p.act != SASPA_ACT_SILU && p.act != SASPA_ACT_RELU && p.act != SASPA_ACT_ADD_RELU) {
     return SASPA_EINVAL;
   }
   if (p.ksplit > 1 && p.workspace && !aligned16(p.workspace)) return SASPA_EALIGN;

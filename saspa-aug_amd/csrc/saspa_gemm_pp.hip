@@ -492,18 +492,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
           const int m = cbm * BM + h * 128 + row, n = cbn * BN + ch * 8;
           if (m >= p.M || n >= p.N) continue;
           u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
-          if (res || p.act == SASPA_ACT_SILU) {
+          if (res || p.act != SASPA_ACT_NONE) {
             float a[8];
             unpack8(__builtin_bit_cast(uint4, c4), a);
             if (p.act == SASPA_ACT_SILU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
+            } else if (p.act == SASPA_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
             }
             if (res) {
               float b[8];
               Elem<bf16_t>::load_chunk(res + (long long)m * p.ldr + n, b);
 #pragma unroll
               for (int e = 0; e < 8; ++e) a[e] += b[e];
+            }
+            if (p.act == SASPA_ACT_ADD_RELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
             }
             c4 = __builtin_bit_cast(u32x4, pack8(a));
           }

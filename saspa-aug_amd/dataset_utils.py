@@ -40,6 +40,11 @@ class BaseUtils:
     def get_basic_prompt(self):
         raise NotImplementedError
 
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """image path -> integer label of the baseline classifier (the confidence filter looks the SOURCE image's label
+        up here, all_utils/utils.py:316, :359).  Must number the classes like the dataset the classifier was trained on."""
+        raise NotImplementedError
+
     def get_image_path_with_same_class(self, image_path: str):
         stem = Path(image_path).stem
         cls = self.image_path_to_class_str_dict[stem]
@@ -78,6 +83,20 @@ class PlanesUtils(BaseUtils):
 
     def get_basic_prompt(self):
         return "a photo of an aircraft"
+
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """torchvision.datasets.FGVCAircraft(annotation_level="variant") numbering (fgvc/datasets/aircraft_dataset.py:19):
+        class id = line number of the variant in data/variants.txt (file order); sorted variant names when that file is
+        absent (the synthetic stand-in)."""
+        variants = utils.load_data(self.root_path / f"images_variant_{split}.txt")
+        vfile = self.root_path / "variants.txt"
+        if vfile.exists():
+            with open(vfile, "r") as f:
+                classes = [ln.strip() for ln in f if ln.strip()]
+        else:
+            classes = sorted(set(variants.values()))
+        idx = {c: i for i, c in enumerate(classes)}
+        return {str(self.images_folder / f"{name}{self.image_ext}"): idx[v] for name, v in variants.items()}
 
 
 class SyntheticUtils(PlanesUtils):
@@ -163,6 +182,14 @@ class CarsUtils(BaseUtils):
     def get_basic_prompt(self):
         return "a photo of a car"
 
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """torchvision.datasets.StanfordCars numbering: annotation class - 1 (fgvc/datasets/car_dataset.py)."""
+        import scipy.io as sio
+        split_to_use = "train" if split == "val" else split
+        ann = sio.loadmat(self.root_path / "devkit" / f"cars_{split_to_use}_annos.mat")["annotations"][0]
+        folder = self.root_path / f"cars_{split_to_use}"
+        return {str(folder / str(a[-1][0])): int(a[4][0][0]) - 1 for a in ann}
+
 
 class _PathKeyedUtils(BaseUtils):
     """Datasets whose class table is keyed by the image PATH (dtd, cub, compcars-parts): the loop looks the sub-class up
@@ -209,6 +236,12 @@ class DTDUtils(_PathKeyedUtils):
     def get_basic_prompt(self):
         return "a photo of a texture"
 
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """torchvision.datasets.DTD numbering: index of the texture in the sorted class list; every image of the dataset
+        (train + val + test of the partition, all_utils/dataset_utils.py:325-336)."""
+        idx = {c: i for i, c in enumerate(sorted({Path(p).parent.name for p in self.all_original_images_paths}))}
+        return {p: idx[Path(p).parent.name] for p in self.all_original_images_paths}
+
 
 class CUBUtils(_PathKeyedUtils):
     """CUB-200-2011 (all_utils/dataset_utils.py:448-490 + fgvc/datasets/cub_dataset.py:41-78): images.txt /
@@ -253,6 +286,19 @@ class CUBUtils(_PathKeyedUtils):
 
     def get_basic_prompt(self):
         return "a photo of a bird"
+
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """image_class_labels.txt label - 1 (fgvc/datasets/cub_dataset.py:47-51)."""
+        label, path = {}, {}
+        with open(self.root_path / "image_class_labels.txt") as f:
+            for line in f:
+                image_id, lb = line.strip().split(" ")
+                label[image_id] = int(lb) - 1
+        with open(self.root_path / "images.txt") as f:
+            for line in f:
+                image_id, rel = line.strip().split(" ")
+                path[image_id] = str(self.root_path / "images" / rel)
+        return {path[i]: label[i] for i in path}
 
 
 class CompCarsPartsUtils(_PathKeyedUtils):
@@ -310,6 +356,16 @@ class CompCarsPartsUtils(_PathKeyedUtils):
 
     def get_image_path_to_class_str_dict(self):
         return {p: self._make_model(p) for p in self.all_original_images_paths}
+
+    def get_image_path_to_class_id_dict(self, split="train"):
+        """Labels of the split CSV numbered by their sorted order (all_utils/dataset_utils.py:413-430)."""
+        rows = []
+        with open(DATASETS_FILES / "compcars-parts" / f"{split}.csv") as f:
+            for line in f:
+                pth, lb = line.strip().split(",")
+                rows.append((str(Path("data/compcars/part") / pth), lb))
+        idx = {lb: i for i, lb in enumerate(sorted({lb for _, lb in rows}))}
+        return {pth: idx[lb] for pth, lb in rows}
 
     def get_basic_prompt(self, part: str = None):
         return f"close up of the {self.part_to_string[str(part)]} of a" if part else "close up of a car"

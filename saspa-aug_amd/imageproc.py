@@ -32,15 +32,24 @@ def _bicubic(x):
     return 0.0
 
 
+def _bilinear(x):
+    x = abs(x)
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+FILTERS = {"bicubic": (_bicubic, 2.0), "bilinear": (_bilinear, 1.0)}       # Pillow's BICUBIC / BILINEAR (filter, support)
+
+
 @lru_cache(maxsize=64)
-def resample_tables(in_len, out_len, first=0, count=None):
-    """Pillow `precompute_coeffs(inSize, 0, inSize, outSize, BICUBIC)` + `normalize_coeffs_8bpc` for output samples
+def resample_tables(in_len, out_len, first=0, count=None, filt="bicubic"):
+    """Pillow `precompute_coeffs(inSize, 0, inSize, outSize, filter)` + `normalize_coeffs_8bpc` for output samples
     [first, first + count): -> (bounds int32 [count, 2], coeffs int32 [count, ksize], ksize)."""
     count = out_len - first if count is None else count
+    kernel, base_support = FILTERS[filt]
     scale = filterscale = in_len / out_len
     if filterscale < 1.0:
         filterscale = 1.0
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((count, 2), np.int32)
     coeffs = np.zeros((count, ksize), np.int32)
@@ -55,7 +64,7 @@ def resample_tables(in_len, out_len, first=0, count=None):
         if xmax > in_len:
             xmax = in_len
         xmax -= xmin
-        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        w = [kernel((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = sum(w)            # left-to-right double sum, like the C loop
         for x in range(xmax):
             v = w[x] / ww if ww != 0.0 else w[x]
@@ -67,15 +76,15 @@ def resample_tables(in_len, out_len, first=0, count=None):
 _DEV_TABLES = {}
 
 
-def _tables_on(dev, in_len, out_len, first, count):
-    key = (str(dev), in_len, out_len, first, count)
+def _tables_on(dev, in_len, out_len, first, count, filt="bicubic"):
+    key = (str(dev), in_len, out_len, first, count, filt)
     if key not in _DEV_TABLES:
-        b, c, k = resample_tables(in_len, out_len, first, count)
+        b, c, k = resample_tables(in_len, out_len, first, count, filt)
         _DEV_TABLES[key] = (torch.from_numpy(b).to(dev), torch.from_numpy(c).to(dev), k)
     return _DEV_TABLES[key]
 
 
-def resample_pass(src, axis, out_len, first=0, count=None):
+def resample_pass(src, axis, out_len, first=0, count=None, filt="bicubic"):
     """One pass over a device u8 [n,H,W,3] tensor along `axis` (1 = rows / vertical, 2 = columns / horizontal)."""
     _check_dev(src)
     if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3 or not src.is_contiguous():
@@ -84,7 +93,7 @@ def resample_pass(src, axis, out_len, first=0, count=None):
     n, h, w, _ = src.shape
     count = out_len - first if count is None else count
     in_len = h if axis == 1 else w
-    bounds, coeffs, ksize = _tables_on(src.device, in_len, out_len, first, count)
+    bounds, coeffs, ksize = _tables_on(src.device, in_len, out_len, first, count, filt)
     if axis == 1:
         dst = torch.empty((n, count, w, 3), device=src.device, dtype=torch.uint8)
         outer, inner = n, w * 3
@@ -96,22 +105,26 @@ def resample_pass(src, axis, out_len, first=0, count=None):
     return dst
 
 
-def resize_bicubic_u8(src, out_h, out_w, crop=None):
-    """PIL.Image.resize((out_w, out_h), BICUBIC) of every image of a device u8 [n,H,W,3] batch, optionally followed by
+def resize_u8(src, out_h, out_w, crop=None, filt="bicubic"):
+    """PIL.Image.resize((out_w, out_h), BICUBIC | BILINEAR) of every image of a device u8 [n,H,W,3] batch, optionally followed by
     the crop (top, left, height, width) -- horizontal pass first, then vertical, like Pillow; a pass whose size does
     not change is skipped, like Pillow."""
     n, h, w, _ = src.shape
     top, left, ch, cw = crop if crop is not None else (0, 0, out_h, out_w)
     x = src
     if out_w != w:
-        x = resample_pass(x, 2, out_w, left, cw)
+        x = resample_pass(x, 2, out_w, left, cw, filt)
     elif (left, cw) != (0, w):
         x = x[:, :, left:left + cw].contiguous()
     if out_h != h:
-        x = resample_pass(x, 1, out_h, top, ch)
+        x = resample_pass(x, 1, out_h, top, ch, filt)
     elif (top, ch) != (0, h):
         x = x[:, top:top + ch].contiguous()
     return x
+
+
+def resize_bicubic_u8(src, out_h, out_w, crop=None):
+    return resize_u8(src, out_h, out_w, crop, "bicubic")
 
 
 def normalize_u8(src, dtype, mean=CLIP_IMAGE_MEAN, std=CLIP_IMAGE_STD):

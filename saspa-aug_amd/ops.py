@@ -15,6 +15,8 @@ ACT_NONE, ACT_SILU = 0, 1
 ACT_QUICK_GELU = 2  # saspa_activation only
 ACT_GELU = 4        # saspa_activation only: erf GELU (BERT / Q-Former)
 ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
+ACT_RELU = 5        # saspa_gemm / saspa_activation: ReLU (before the residual add)
+ACT_ADD_RELU = 6    # saspa_gemm only: ReLU AFTER the residual add (ResNet bottleneck)
 GEMM_AUTO, GEMM_TILED, GEMM_WIDE = 0, 1, 2   # SaspaGemmParams.variant
 
 
@@ -198,10 +200,10 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     return out
 
 
-def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=1.0):
-    """Raw batched GEMM out[z] = alpha * a[z] @ w[z]^T; s* = (stride1, stride2) in elements.
-    ``a``/``w``/``out`` are tensors whose data_ptr is the z=0 origin."""
-    _check_dev(a, w, out)
+def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=1.0, residual=None, ldr=0, act=ACT_NONE):
+    """Raw batched GEMM out[z] = act(alpha * a[z] @ w[z]^T) (+ residual[z], same batch strides as out); s* = (stride1,
+    stride2) in elements.  ``a``/``w``/``out``/``residual`` are tensors whose data_ptr is the z=0 origin."""
+    _check_dev(a, w, out, residual)
     lib = _lib.load()
     p = _lib.GemmParams()
     p.dtype = _dt(a)
@@ -211,9 +213,10 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.pad = p.upsample = 0
     p.w, p.ldw = _ptr(w), ldw
     p.M, p.N, p.K = m, n, k
-    p.bias = p.rowvec = p.residual = None
-    p.ldrv = p.ldr = 0
-    p.alpha, p.act = float(alpha), 0
+    p.bias = p.rowvec = None
+    p.residual, p.ldr = _ptr(residual), int(ldr)
+    p.ldrv = 0
+    p.alpha, p.act = float(alpha), int(act)
     p.out, p.ldo = _ptr(out), ldo
     p.nb1, p.nb2 = nb1, nb2
     p.sa1, p.sa2 = sa
@@ -334,6 +337,29 @@ def activation(x, act, out=None):
     rows = x2.shape[0]
     _lib.check(lib.saspa_activation(_dt(x), int(act), _ptr(x2), x2.stride(0) if rows > 1 else c, _ptr(o2),
                                     o2.stride(0) if rows > 1 else c, rows, c, _stream()), "saspa_activation")
+    return out
+
+
+def pool2d(x, k, stride=None, pad=0, mode="avg"):
+    """nn.MaxPool2d(k, stride, pad) / nn.AvgPool2d(k) over channels-last x [B,H,W,C] -> [B,Ho,Wo,C]."""
+    _check_dev(x)
+    stride = k if stride is None else stride
+    b, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((b, ho, wo, c), device=x.device, dtype=x.dtype)
+    _lib.check(_lib.load().saspa_pool2d(_dt(x), 0 if mode == "max" else 1, _ptr(x), _pitch4(x), _ptr(out), c, b, h, w, c, int(k),
+                                        int(stride), int(pad), _stream()), "saspa_pool2d")
+    return out
+
+
+def signsqrt_l2norm(x, eps, scale=1.0):
+    """rows of fp32 [R, C]: scale * normalize(sign(x) * sqrt(|x| + eps)) (WSDAN bilinear attention pooling tail)."""
+    _check_dev(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("signsqrt_l2norm expects an fp32 [rows, C] matrix")
+    out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().saspa_signsqrt_l2norm(_ptr(x), x.stride(0), _ptr(out), out.stride(0), x.shape[0], x.shape[1], float(eps),
+                                                 float(scale), _stream()), "saspa_signsqrt_l2norm")
     return out
 
 

@@ -490,9 +490,10 @@ def load_source(path, resolution):
     return utils.resize_image(np.array(img), resolution)
 
 
-def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None):
+def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None, filter_models=None):
     """The generation loop.  `batch_generator` is injectable for host-logic tests; the default
-    builds the HIP pipeline (fails loudly without an MI355X)."""
+    builds the HIP pipeline (fails loudly without an MI355X).  `filter_models` = (SemanticFilter | None,
+    ConfidenceFilter | None) to reuse built filter models; None builds them on s.DEVICE when a filter flag is set."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     png = _PngWriters(4)
@@ -652,10 +653,12 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None)
         logging.info(f"Done Generating: {(status == 1).sum().item()} generated, {(status == -1).sum().item()} failed, "
                      f"{sum(i.skip for i in items)} skipped (already existed)")
         n_files = len(list(Path(output_folder).glob("*.*")))
+        fdev = torch.device(s.DEVICE) if (s.SEMANTIC_FILTERING or s.MODEL_CONFIDENCE_BASED_FILTERING) and filter_models is None else None
         json_path = utils.create_json_of_image_name_to_augmented_images_paths(
             ds_utils, output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
             model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING, init_log=False,
-            original_images_paths=ds_utils.original_images_paths, min_files=min(10, max(1, n_files)))
+            original_images_paths=ds_utils.original_images_paths, min_files=min(10, max(1, n_files)),
+            filter_models=filter_models, weights_dir=s.WEIGHTS_DIR, device=fdev)
     if dist is not None:
         dist.barrier()
     return dict(items=items, status=status, json_path=json_path, output_folder=output_folder)

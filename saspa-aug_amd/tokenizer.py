@@ -19,15 +19,16 @@ import numpy as np
 
 
 class HashTokenizer:
-    def __init__(self, vocab=49408, max_len=77):
+    def __init__(self, vocab=49408, max_len=77, pad_id=None):
         self.vocab, self.max_len = vocab, max_len
         self.bos, self.eos = vocab - 2, vocab - 1
+        self.pad = self.eos if pad_id is None else pad_id
 
     def __call__(self, text, max_len=None):
         max_len = max_len or self.max_len
         words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", (text or "").lower())
         ids = [self.bos] + [zlib.crc32(w.encode()) % (self.vocab - 2) for w in words][: max_len - 2] + [self.eos]
-        ids += [self.eos] * (max_len - len(ids))
+        ids += [self.pad] * (max_len - len(ids))
         return np.asarray(ids, np.int64)[None]
 
 
@@ -45,7 +46,7 @@ def _bytes_to_unicode():
 
 
 class CLIPBPETokenizer:
-    def __init__(self, vocab_dir, max_len=77):
+    def __init__(self, vocab_dir, max_len=77, pad_id=None):
         with open(os.path.join(vocab_dir, "vocab.json"), encoding="utf-8") as f:
             self.encoder = json.load(f)
         with open(os.path.join(vocab_dir, "merges.txt"), encoding="utf-8") as f:
@@ -54,6 +55,7 @@ class CLIPBPETokenizer:
         self.byte_enc = _bytes_to_unicode()
         self.max_len = max_len
         self.bos, self.eos = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+        self.pad = self.eos if pad_id is None else pad_id      # HF CLIPTokenizer pads with EOS, OpenAI's clip.tokenize with 0
         # CLIP's pre-tokenisation pattern (openai/CLIP simple_tokenizer.py, transformers CLIPTokenizer): unicode letter /
         # number classes need the `regex` module -- `[a-z]+` would split accented sub-class names into punctuation tokens
         import regex
@@ -96,14 +98,14 @@ class CLIPBPETokenizer:
             tok = "".join(self.byte_enc[b] for b in tok.encode("utf-8"))
             ids += [self.encoder.get(p, unk) for p in self._bpe(tok)]
         ids = [self.bos] + ids[: max_len - 2] + [self.eos]
-        ids += [self.eos] * (max_len - len(ids))
+        ids += [self.pad] * (max_len - len(ids))
         return np.asarray(ids, np.int64)[None]
 
 
-def make_tokenizer(vocab_dir=None, vocab=49408):
+def make_tokenizer(vocab_dir=None, vocab=49408, pad_id=None):
     if vocab_dir and os.path.exists(os.path.join(vocab_dir, "vocab.json")):
-        return CLIPBPETokenizer(vocab_dir)
-    return HashTokenizer(vocab)
+        return CLIPBPETokenizer(vocab_dir, pad_id=pad_id)
+    return HashTokenizer(vocab, pad_id=pad_id)
 
 
 # ---- BERT tokenizer of the BLIP-Diffusion Q-Former (subject category text, e.g. "bird") ----------------------

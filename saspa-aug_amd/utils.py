@@ -5,9 +5,10 @@ interface for this path (same names, argument meaning and outputs):
   HWC3 / resize_image           all_utils/utils.py:39-79
   generate_canny (+ preprocess_canny, CannyDetector -> HIP kernel)   all_utils/utils.py:81-109
   get_aug_json_path             all_utils/utils.py:194-218
-  create_json_of_image_name_to_augmented_images_paths   all_utils/utils.py:221-465 (the
-        non-filter part: PNG integrity sweep, stem matching, JSON layout; the CLIP / classifier
-        filters inside it are SURVEY 8(f) "next" rows and raise NotImplementedError if enabled)
+  create_json_of_image_name_to_augmented_images_paths   all_utils/utils.py:221-465 (PNG integrity
+        sweep, stem matching, JSON layout, and the semantic / model-confidence filters, which run
+        on the gfx950 kernels: saspa_aug_amd/filters.py; LPIPS / per-class CLIP / ALIA filters are
+        baseline branches and raise NotImplementedError)
   check_folder_of_images_with_pil   all_utils/utils.py:681-703
   init_logging                  all_utils/utils.py:593-612
 
@@ -169,7 +170,7 @@ def create_json_of_image_name_to_augmented_images_paths(dataset, augmented_image
                                                         semantic_filtering=False, model_confidence_based_filtering=False,
                                                         conf_top_k: int = 10, filter_confidence_higher_than: int = None,
                                                         init_log=True, alia_conf_filtering=False, original_images_paths=None,
-                                                        min_files=10):
+                                                        min_files=10, filter_models=None, weights_dir=None, device=None):
     """`dataset` may be a dataset name (resolved through dataset_utils.DS_UTILS_DICT) or any
     object with `.original_images_paths`."""
     assert not (clip_filtering and model_confidence_based_filtering)
@@ -194,11 +195,28 @@ def create_json_of_image_name_to_augmented_images_paths(dataset, augmented_image
                                 f"than {min_files} images")
     mapping = match_augmented_images(original_images_paths, os.listdir(augmented_image_folder_path), augmented_image_folder_path)
     if semantic_filtering or model_confidence_based_filtering:
-        # The filter models (CLIP RN50, the CAL baseline classifier) are the "next" row f1 of
-        # SURVEY section 8; the file NAME still encodes the requested filters so the training
-        # scripts find it (fgvc/trainings_scripts/consecutive_runs_aug.sh:10), and the log says so.
-        logging.info("semantic / model-confidence filters requested: NOT applied by this build (SURVEY 8(f) f1); "
-                     "json contains the unfiltered lists")
+        # the filter stage: CLIP-RN50 semantic filter + baseline-classifier top-k filter on the gfx950 kernels
+        from . import filters
+        if isinstance(dataset, str):
+            from . import dataset_utils
+            dataset = dataset_utils.DS_UTILS_DICT[dataset](print_func=logging.info)
+        if filter_models is None:
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+            if device is None:
+                raise RuntimeError("the semantic / model-confidence filters run on the MI355X only (no CPU path); pass "
+                                   "semantic_filtering=0, model_confidence_based_filtering=0 to write the unfiltered aug.json")
+            filter_models = filters.build_filters(dataset, device, bool(semantic_filtering), bool(model_confidence_based_filtering),
+                                                  weights_dir, conf_top_k)
+        sem, conf = filter_models
+        if filter_confidence_higher_than:
+            raise NotImplementedError("filter_confidence_higher_than is an ablation knob of the reference (unused by run_aug)")
+        mapping, counters = filters.apply_filters(mapping, original_images_paths, dataset, device, sem if semantic_filtering else None,
+                                                  conf if model_confidence_based_filtering else None)
+        if semantic_filtering:
+            logging.info(f"For filter = semantic_filtering, filtered {counters['semantic']} images")
+        if model_confidence_based_filtering:
+            logging.info(f"For filter = not_in_top_{conf_top_k}, filtered {counters['not_in_top_k']} images")
     Path(json_path).parent.mkdir(parents=True, exist_ok=True)
     with open(json_path, "w") as f:
         json.dump(mapping, f)

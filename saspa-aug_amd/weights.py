@@ -244,6 +244,117 @@ SPECS = dict(safety=safety_checker_spec, unet=unet_spec, controlnet=controlnet_s
              qformer=blip2_qformer_spec)
 
 
+def _bn(spec, pfx, c):
+    spec += [(pfx + ".weight", (c,), "gain"), (pfx + ".bias", (c,), "bias"), (pfx + ".running_mean", (c,), "bias"),
+             (pfx + ".running_var", (c,), "var")]
+
+
+def clip_rn50_spec(cfg):
+    """OpenAI CLIP RN50 state dict (ModifiedResNet + AttentionPool2d under `visual.`, text transformer, projections)."""
+    spec = []
+    w = cfg["width"]
+    v = "visual"
+    for i, (ci, co) in enumerate(((3, w // 2), (w // 2, w // 2), (w // 2, w))):
+        spec.append((f"{v}.conv{i + 1}.weight", (co, ci, 3, 3), "w"))
+        _bn(spec, f"{v}.bn{i + 1}", co)
+    inpl = w
+    for li, nb in enumerate(cfg["layers"]):
+        planes = w * (2 ** li)
+        for bi in range(nb):
+            pf = f"{v}.layer{li + 1}.{bi}"
+            stride = 2 if (bi == 0 and li > 0) else 1
+            spec.append((pf + ".conv1.weight", (planes, inpl, 1, 1), "w"))
+            _bn(spec, pf + ".bn1", planes)
+            spec.append((pf + ".conv2.weight", (planes, planes, 3, 3), "w"))
+            _bn(spec, pf + ".bn2", planes)
+            spec.append((pf + ".conv3.weight", (planes * 4, planes, 1, 1), "w"))
+            _bn(spec, pf + ".bn3", planes * 4)
+            if stride > 1 or inpl != planes * 4:
+                spec.append((pf + ".downsample.0.weight", (planes * 4, inpl, 1, 1), "w"))
+                _bn(spec, pf + ".downsample.1", planes * 4)
+            inpl = planes * 4
+    a = v + ".attnpool"
+    sp = (cfg["image_size"] // 32) ** 2 + 1
+    spec.append((a + ".positional_embedding", (sp, inpl), "pos"))
+    for n, co in (("q_proj", inpl), ("k_proj", inpl), ("v_proj", inpl), ("c_proj", cfg["embed_dim"])):
+        spec += [(f"{a}.{n}.weight", (co, inpl), "w"), (f"{a}.{n}.bias", (co,), "bias")]
+    tw = cfg["text_width"]
+    spec += [("token_embedding.weight", (cfg["vocab"], tw), "emb"), ("positional_embedding", (cfg["context"], tw), "pos")]
+    for i in range(cfg["text_layers"]):
+        pf = f"transformer.resblocks.{i}"
+        spec += [(pf + ".attn.in_proj_weight", (3 * tw, tw), "w"), (pf + ".attn.in_proj_bias", (3 * tw,), "bias"),
+                 (pf + ".attn.out_proj.weight", (tw, tw), "w"), (pf + ".attn.out_proj.bias", (tw,), "bias"),
+                 (pf + ".ln_1.weight", (tw,), "gain"), (pf + ".ln_1.bias", (tw,), "bias"),
+                 (pf + ".ln_2.weight", (tw,), "gain"), (pf + ".ln_2.bias", (tw,), "bias"),
+                 (pf + ".mlp.c_fc.weight", (4 * tw, tw), "w"), (pf + ".mlp.c_fc.bias", (4 * tw,), "bias"),
+                 (pf + ".mlp.c_proj.weight", (tw, 4 * tw), "w"), (pf + ".mlp.c_proj.bias", (tw,), "bias")]
+    spec += [("ln_final.weight", (tw,), "gain"), ("ln_final.bias", (tw,), "bias"),
+             ("text_projection", (tw, cfg["embed_dim"]), "wt"), ("logit_scale", (), "logit_scale")]
+    return spec
+
+
+def wsdan_cal_spec(cfg):
+    """WSDAN_CAL state dict (fgvc/models/cal.py:131-166): `features` = Sequential(conv1, bn1, relu, maxpool, layer1..4) of the
+    fgvc ResNet (keys features.0 / .1 / .4 .. .7), `attentions` = BasicConv2d (1x1 conv + BN), `fc` (no bias)."""
+    spec = []
+    w = cfg["width"]
+    spec.append(("features.0.weight", (w, 3, 7, 7), "w"))
+    _bn(spec, "features.1", w)
+    inpl = w
+    for li, nb in enumerate(cfg["layers"]):
+        planes = w * (2 ** li)
+        for bi in range(nb):
+            pf = f"features.{4 + li}.{bi}"
+            stride = (1, 2, 2, 1)[li] if bi == 0 else 1      # layer4 unstrided (fgvc ResNet stride=1)
+            spec.append((pf + ".conv1.weight", (planes, inpl, 1, 1), "w"))
+            _bn(spec, pf + ".bn1", planes)
+            spec.append((pf + ".conv2.weight", (planes, planes, 3, 3), "w"))
+            _bn(spec, pf + ".bn2", planes)
+            spec.append((pf + ".conv3.weight", (planes * 4, planes, 1, 1), "w"))
+            _bn(spec, pf + ".bn3", planes * 4)
+            if stride != 1 or inpl != planes * 4:
+                spec.append((pf + ".downsample.0.weight", (planes * 4, inpl, 1, 1), "w"))
+                _bn(spec, pf + ".downsample.1", planes * 4)
+            inpl = planes * 4
+    m = cfg["attentions"]
+    spec.append(("attentions.conv.weight", (m, inpl, 1, 1), "w"))
+    _bn(spec, "attentions.bn", m)
+    spec.append(("fc.weight", (cfg["num_classes"], m * inpl), "w_fc"))
+    return spec
+
+
+SPECS.update(clip_rn50=clip_rn50_spec, cal=wsdan_cal_spec)
+
+
+def fold_bn(conv_w, sd, bn_pfx, eps=1e-5):
+    """Inference BatchNorm folded into the preceding bias-free conv: (w * s[:, None, None, None], beta - mean * s) with
+    s = gamma / sqrt(var + eps) -- computed in fp64, stored fp32."""
+    g, b = sd[bn_pfx + ".weight"].double(), sd[bn_pfx + ".bias"].double()
+    m, v = sd[bn_pfx + ".running_mean"].double(), sd[bn_pfx + ".running_var"].double()
+    s = g / torch.sqrt(v + eps)
+    return (conv_w.double() * s.reshape(-1, *([1] * (conv_w.dim() - 1)))).float(), (b - m * s).float()
+
+
+def openai_clip_text_to_hf(sd, layers):
+    """OpenAI CLIP text-tower keys (transformer.resblocks.N.attn.in_proj_weight ...) -> the transformers names the CLIPText
+    launch graph packs (text_model.encoder.layers.N.self_attn.q_proj.weight ...); text_projection is stored [width, embed]
+    by OpenAI and applied as x @ P, i.e. the Linear weight is its transpose."""
+    out = {"text_model.embeddings.token_embedding.weight": sd["token_embedding.weight"],
+           "text_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+           "text_model.final_layer_norm.weight": sd["ln_final.weight"], "text_model.final_layer_norm.bias": sd["ln_final.bias"],
+           "text_projection.weight": sd["text_projection"].t().contiguous()}
+    for i in range(layers):
+        a, b = f"transformer.resblocks.{i}", f"text_model.encoder.layers.{i}"
+        wq, wk, wv = sd[a + ".attn.in_proj_weight"].chunk(3, dim=0)
+        bq, bk, bv = sd[a + ".attn.in_proj_bias"].chunk(3, dim=0)
+        for n, w_, b_ in (("q_proj", wq, bq), ("k_proj", wk, bk), ("v_proj", wv, bv)):
+            out[f"{b}.self_attn.{n}.weight"], out[f"{b}.self_attn.{n}.bias"] = w_.contiguous(), b_.contiguous()
+        out[b + ".self_attn.out_proj.weight"], out[b + ".self_attn.out_proj.bias"] = sd[a + ".attn.out_proj.weight"], sd[a + ".attn.out_proj.bias"]
+        for src, dst in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            out[f"{b}.{dst}.weight"], out[f"{b}.{dst}.bias"] = sd[f"{a}.{src}.weight"], sd[f"{a}.{src}.bias"]
+    return out
+
+
 def synth_state_dict(kind, cfg, seed=0):
     """Seeded synthetic fp32 state dict with diffusers key names."""
     g = torch.Generator().manual_seed(seed)
@@ -258,6 +369,16 @@ def synth_state_dict(kind, cfg, seed=0):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif k == "bias":
             t = 0.05 * torch.randn(shape, generator=g)
+        elif k == "var":            # BatchNorm running variance: positive, around 1
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif k == "pos":            # position tables of width shape[-1]
+            t = torch.randn(shape, generator=g) / math.sqrt(shape[-1])
+        elif k == "wt":             # [in, out] projection applied as x @ P
+            t = torch.randn(shape, generator=g) / math.sqrt(shape[0])
+        elif k == "w_fc":           # classifier over unit-norm x 100 features: keeps the logits O(1) apart
+            t = torch.randn(shape, generator=g) * 0.05
+        elif k == "logit_scale":
+            t = torch.tensor(math.log(100.0))
         elif k == "thresh":
             # cosine thresholds of the safety checker (the real ones lie around 0.18-0.3): 6 sigma of the cosine of two
             # random proj_dim-vectors (0.217 at 768) so that random weights never flag an image by accident

@@ -275,6 +275,19 @@ int saspa_pool2d(int dtype, int mode, const void* x, int ldx, void* y, int ldy, 
 int saspa_signsqrt_l2norm(const float* x, long long ldx, float* y, long long ldy, int rows, long long C, float eps,
                           float scale, void* stream);
 
+/* ---- cv2.resize, 8-bit RGB [n][h][w][3] -> [n][dh][dw][3] (all_utils/utils.py:58-79 `resize_image`) -------
+ * saspa_resize_taps_u8: OpenCV's separable fixed-point filters; xofs / yofs = first tap index per destination sample,
+ * xw / yw = ntaps 11-bit weights per destination sample.  mode 0 = INTER_LANCZOS4 (ntaps 8), mode 1 = the 8-bit bilinear
+ * code INTER_AREA falls back to when a side is up-scaled (ntaps 2).  Out-of-image taps are clamped (replicate).
+ * saspa_resize_area_u8: INTER_AREA down-scaling.  isx, isy > 0: integer scale factors (resizeAreaFast_), tables unused;
+ * otherwise CSR-style tables from computeResizeAreaTab: destination sample d owns entries [start[d], start[d+1]) of
+ * (source index, float weight); accumulation order and float roundings follow resizeArea_<uchar, float>. */
+int saspa_resize_taps_u8(const uint8_t* src, uint8_t* dst, int n, int h, int w, int dh, int dw, const int* xofs,
+                         const short* xw, const int* yofs, const short* yw, int ntaps, int mode, void* stream);
+int saspa_resize_area_u8(const uint8_t* src, uint8_t* dst, int n, int h, int w, int dh, int dw, const int* xstart,
+                         const int* xsi, const float* xalpha, const int* ystart, const int* ysi, const float* ybeta,
+                         int isx, int isy, void* stream);
+
 /* library self-description */
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);

@@ -149,3 +149,130 @@ def clip_image_preprocess(src, dtype, size=224):
     top, left = (oh - size) // 2, (ow - size) // 2
     x = resize_bicubic_u8(src.contiguous(), oh, ow, crop=(top, left, size, size))
     return normalize_u8(x, dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cv2.resize (8-bit RGB) as the reference's `resize_image` calls it (all_utils/utils.py:58-79): the tables
+# are host set-up in OpenCV's own arithmetic (float32 source coordinates and weights, 11-bit fixed point, double-precision
+# area cells); all pixel work runs in saspa_resize_taps_u8 / saspa_resize_area_u8.
+# ---------------------------------------------------------------------------------------------------------------------
+_COEF_SCALE = np.float32(2048.0)          # INTER_RESIZE_COEF_SCALE (11 bits)
+
+
+def _lanczos4_weights(x):
+    """OpenCV interpolateLanczos4(float x, float* coeffs)."""
+    s45 = 0.70710678118654752440084436210485
+    cs = ((1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45))
+    c = np.zeros(8, np.float32)
+    if x < np.finfo(np.float32).eps:
+        c[3] = 1.0
+        return c
+    xd = float(x)
+    y0 = -(xd + 3) * math.pi * 0.25
+    s0, c0 = math.sin(y0), math.cos(y0)
+    total = np.float32(0)
+    for i in range(8):
+        y = -(xd + 3 - i) * math.pi * 0.25
+        c[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
+        total = np.float32(total + c[i])
+    return (c * np.float32(np.float32(1.0) / total)).astype(np.float32)
+
+
+def _fix(weights):
+    return np.clip(np.rint(weights.astype(np.float32) * _COEF_SCALE), -32768, 32767).astype(np.int16)     # saturate_cast<short>
+
+
+@lru_cache(maxsize=256)
+def cv_tap_tables(ssize, dsize, mode):
+    """mode "lanczos4": first tap sx - 3 and 8 weights per destination sample; mode "area_linear": the bilinear taps of
+    INTER_AREA's up-scaling branch (`area_mode` coordinates)."""
+    scale = ssize / float(dsize)
+    inv = dsize / float(ssize)
+    nt = 8 if mode == "lanczos4" else 2
+    ofs = np.zeros(dsize, np.int32)
+    w = np.zeros((dsize, nt), np.int16)
+    for d in range(dsize):
+        if mode == "lanczos4":
+            fx = np.float32((d + 0.5) * scale - 0.5)
+            sx = int(math.floor(float(fx)))
+            fx = np.float32(fx - np.float32(sx))
+            ofs[d], w[d] = sx - 3, _fix(_lanczos4_weights(fx))
+        else:
+            sx = int(math.floor(d * scale))
+            fx = np.float32((d + 1) - (sx + 1) * inv)
+            fx = np.float32(0.0) if fx <= 0 else np.float32(fx - np.float32(math.floor(float(fx))))
+            if sx < 0:
+                fx, sx = np.float32(0.0), 0
+            if sx >= ssize - 1:
+                fx, sx = np.float32(0.0), ssize - 1
+            ofs[d], w[d] = sx, _fix(np.array([np.float32(1.0) - fx, fx], np.float32))
+    return ofs, w
+
+
+@lru_cache(maxsize=256)
+def cv_area_tables(ssize, dsize):
+    """OpenCV computeResizeAreaTab as CSR: (start [dsize + 1], source index [nnz], float32 weight [nnz])."""
+    scale = ssize / float(dsize)
+    start, si, al = [0], [], []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = math.ceil(fsx1), math.floor(fsx2)
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            si.append(sx1 - 1)
+            al.append(np.float32((sx1 - fsx1) / cell))
+        for sx in range(sx1, sx2):
+            si.append(sx)
+            al.append(np.float32(1.0 / cell))
+        if fsx2 - sx2 > 1e-3:
+            si.append(sx2)
+            al.append(np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell))
+        start.append(len(si))
+    return np.asarray(start, np.int32), np.asarray(si, np.int32), np.asarray(al, np.float32)
+
+
+_CV_DEV = {}
+
+
+def _cv_dev(dev, key, build):
+    k = (str(dev),) + key
+    if k not in _CV_DEV:
+        _CV_DEV[k] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in build())
+    return _CV_DEV[k]
+
+
+def cv_resize_u8(src, dh, dw, interpolation):
+    """cv2.resize(src, (dw, dh), interpolation=INTER_LANCZOS4 | INTER_AREA) of a device u8 [n,H,W,3] batch."""
+    _check_dev(src)
+    if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3 or not src.is_contiguous():
+        raise ValueError("cv_resize_u8 expects a contiguous u8 [n,H,W,3] tensor")
+    n, h, w, _ = src.shape
+    if (h, w) == (dh, dw):
+        return src
+    lib = _lib.load()
+    dst = torch.empty((n, dh, dw, 3), device=src.device, dtype=torch.uint8)
+    if interpolation == "lanczos4" or (interpolation == "area" and (w / float(dw) < 1 or h / float(dh) < 1)):
+        mode = "lanczos4" if interpolation == "lanczos4" else "area_linear"
+        xo, xw = _cv_dev(src.device, ("tap", w, dw, mode), lambda: cv_tap_tables(w, dw, mode))
+        yo, yw = _cv_dev(src.device, ("tap", h, dh, mode), lambda: cv_tap_tables(h, dh, mode))
+        _lib.check(lib.saspa_resize_taps_u8(_ptr(src), _ptr(dst), n, h, w, dh, dw, _ptr(xo), _ptr(xw), _ptr(yo), _ptr(yw),
+                                            8 if mode == "lanczos4" else 2, 0 if mode == "lanczos4" else 1, _stream()),
+                   "saspa_resize_taps_u8")
+        return dst
+    if interpolation != "area":
+        raise ValueError(f"unsupported interpolation {interpolation!r}")
+    sx, sy = w / float(dw), h / float(dh)
+    isx, isy = int(round(sx)), int(round(sy))
+    eps = np.finfo(np.float64).eps
+    if abs(sx - isx) < eps and abs(sy - isy) < eps:                        # resizeAreaFast_
+        _lib.check(lib.saspa_resize_area_u8(_ptr(src), _ptr(dst), n, h, w, dh, dw, None, None, None, None, None, None, isx, isy,
+                                            _stream()), "saspa_resize_area_u8")
+        return dst
+    xs, xi, xa = _cv_dev(src.device, ("area", w, dw), lambda: cv_area_tables(w, dw))
+    ys, yi, ya = _cv_dev(src.device, ("area", h, dh), lambda: cv_area_tables(h, dh))
+    _lib.check(lib.saspa_resize_area_u8(_ptr(src), _ptr(dst), n, h, w, dh, dw, _ptr(xs), _ptr(xi), _ptr(xa), _ptr(ys), _ptr(yi),
+                                        _ptr(ya), 0, 0, _stream()), "saspa_resize_area_u8")
+    return dst

@@ -460,7 +460,13 @@ class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
         self._need_device()
         from .blip import preprocess_reference
         qc = self.cfgs["qformer"]
-        px = torch.stack([preprocess_reference(im, qc, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD) for im in reference_images])
+        def one(im):
+            if torch.is_tensor(im) and im.is_cuda:          # device u8 [H,W,3] (run_aug): Pillow-exact bicubic on the device
+                from . import imageproc
+                x = imageproc.resize_u8(im[None].contiguous(), qc["image_size"], qc["image_size"], filt="bicubic")
+                return imageproc.normalize_u8(x, torch.float32, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD)[0, :, :, :3].permute(2, 0, 1)
+            return preprocess_reference(im, qc, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD).to(self.device)
+        px = torch.stack([one(im) for im in reference_images])
         ids = [self.qformer_tokenizer(c) for c in source_subject_categories]
         if len({i.shape[1] for i in ids}) == 1:
             return self.qformer.forward(px, np.concatenate(ids))

@@ -445,15 +445,32 @@ def hip_batch_generator(pipe, s: Settings):
 
     side = torch.cuda.Stream(device=pipe.device)
 
+    def to_device(raw, height, width):
+        """One decoded source image (host u8 [h,w,3], any size) -> device u8 [height,width,3]: `resize_image`
+        (all_utils/utils.py:58-79) on the device, stream-ordered -- nothing here waits for the GPU."""
+        from . import imageproc
+        d = ops.h2d(torch.from_numpy(np.ascontiguousarray(raw)), pipe.device)
+        if tuple(d.shape[:2]) == (height, width):
+            return d
+        _, _, k = utils.resize_target_size(d.shape[0], d.shape[1], s.RESOLUTION)
+        return imageproc.cv_resize_u8(d[None].contiguous(), height, width, "lanczos4" if k > 1 else "area")[0]
+
     def enqueue(batch, noises, sources, subjects=None, category=None):
-        """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU."""
-        src = ops.h2d(torch.from_numpy(np.ascontiguousarray(sources)), pipe.device)
+        """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU.  `sources` /
+        `subjects`: decoded images as loaded (lists; a stacked array when they already have the planned size)."""
+        src = torch.stack([to_device(raw, it.height, it.width) for raw, it in zip(sources, batch)])
         ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
         lat = torch.cat(noises)
+        subs = None
         if blip:
             # subject tokens from the same-class image (or the image itself), amplified "a {category} {prompt}" prompt
             # tokenised to 77 - 16 tokens, no conditioning scale (run_aug/run_aug.py:243-250, 262-265, 444-456)
-            refs = subjects if subjects is not None else list(sources)
+            if subjects is not None:
+                subs = []
+                for raw in subjects:
+                    th, tw, _ = utils.resize_target_size(raw.shape[0], raw.shape[1], s.RESOLUTION)
+                    subs.append(to_device(raw, th, tw))
+            refs = subs if subs is not None else list(src)
             q = pipe.get_query_embeddings(refs, [category] * len(batch))
             ids = np.concatenate([tok(pipe.build_prompt(it.prompt, category), max_len=pipe.prompt_token_count()) for it in batch])
             out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE, 1.0, query_embeds=q)
@@ -463,18 +480,20 @@ def hip_batch_generator(pipe, s: Settings):
                                       s.CONTROLNET_CONDITIONING_SCALE)
         ev = torch.cuda.Event()
         ev.record()
-        return out, ctrl, ev
+        return out, ctrl, ev, src, subs
 
     def finish(handle):
         """Device -> host copies of a batch enqueued earlier, on a side stream that waits for THAT batch only: the next
-        batch's launch sequence may already be queued behind it on the main stream and keeps the GPU busy meanwhile."""
-        out, ctrl, ev = handle
+        batch's launch sequence may already be queued behind it on the main stream and keeps the GPU busy meanwhile.
+        -> (images, controls, resized sources, resized subjects | None)."""
+        out, ctrl, ev, src, subs = handle
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            out.record_stream(side)
-            ctrl.record_stream(side)
-            o, c = out.cpu(), ctrl.cpu()
-        return o.numpy(), c.numpy()
+            for t in (out, ctrl, src) + tuple(subs or ()):
+                t.record_stream(side)
+            o, c, sr = out.cpu(), ctrl.cpu(), src.cpu()
+            sb = [t.cpu().numpy() for t in subs] if subs is not None else None
+        return o.numpy(), c.numpy(), sr.numpy(), sb
 
     def run(batch, noises, sources, subjects=None, category=None):
         return finish(enqueue(batch, noises, sources, subjects, category))
@@ -483,11 +502,16 @@ def hip_batch_generator(pipe, s: Settings):
     return run
 
 
-def load_source(path, resolution):
-    """diffusers.utils.load_image + utils.resize_image (run_aug/run_aug.py:372-374)."""
+def load_raw(path):
+    """diffusers.utils.load_image (run_aug/run_aug.py:372): open, EXIF-transpose, RGB -> u8 [h,w,3]."""
     from PIL import ImageOps
-    img = ImageOps.exif_transpose(Image.open(path)).convert("RGB")
-    return utils.resize_image(np.array(img), resolution)
+    return np.array(ImageOps.exif_transpose(Image.open(path)).convert("RGB"))
+
+
+def load_source(path, resolution):
+    """diffusers.utils.load_image + utils.resize_image (run_aug/run_aug.py:372-374) for ONE image (the generation loop
+    resizes on the device inside the batch instead: hip_batch_generator.to_device)."""
+    return utils.resize_image(load_raw(path), resolution)
 
 
 def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None, filter_models=None):
@@ -549,10 +573,12 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     num_errors = 0
 
     def load_batch(batch):
-        """Decode + resize the batch's source (and subject) images: host work, prefetched one batch ahead on its own
-        thread so the GPU does not wait for JPEG decoding between launch sequences."""
-        srcs = np.stack([load_source(it.source_path, s.RESOLUTION) for it in batch])
-        subs = [load_source(it.subject_path, s.RESOLUTION) if it.subject_path else srcs[k] for k, it in enumerate(batch)] if blip else None
+        """Decode the batch's source (and subject) images: host work, prefetched one batch ahead on its own thread so the
+        GPU does not wait for JPEG decoding between launch sequences (the resize runs on the device, in `enqueue`)."""
+        srcs = [load_raw(it.source_path) for it in batch]
+        subs = [load_raw(it.subject_path) if it.subject_path else srcs[k] for k, it in enumerate(batch)] if blip else None
+        if all(r.shape[:2] == (it.height, it.width) for r, it in zip(srcs, batch)):
+            srcs = np.stack(srcs)            # already at the planned size: what injected (host-only) generators consume
         return srcs, subs
 
     loader = ThreadPoolExecutor(max_workers=1)
@@ -573,11 +599,11 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     def drain(entry):
         batch, handle, sources, subjects = entry
         try:
-            images, controls = batch_generator.finish(handle)
+            images, controls, resized, resized_subjects = batch_generator.finish(handle)
         except RuntimeError as e:
             failed(batch, e)
             return False
-        emit(batch, images, controls, sources, subjects)
+        emit(batch, images, controls, resized, resized_subjects if subjects is not None else None)
         return True
 
     def emit(batch, images, controls, sources, subjects):

@@ -70,15 +70,18 @@ def resize_target_size(h, w, smaller_side_res):
 
 
 def resize_image(input_image, smaller_side_res):
-    """Same target size as the reference.  Resampling: the reference uses cv2 Lanczos4 /
-    INTER_AREA fixed-point kernels, which are not reproduced bit-for-bit here (SURVEY 8(f)
-    row f2); PIL LANCZOS / BOX are the closest stock filters.  Identity when already sized."""
+    """all_utils/utils.py:58-79: target size as the reference computes it, cv2.resize semantics (INTER_LANCZOS4 when the
+    final scale k > 1, INTER_AREA otherwise) through the gfx950 kernels (saspa_resize_taps_u8 / saspa_resize_area_u8).
+    Identity (no device needed) when the image already has the target size.  numpy u8 [H,W,3] in and out."""
     H, W, _ = input_image.shape
     th, tw, k = resize_target_size(H, W, smaller_side_res)
     if (th, tw) == (H, W):
         return input_image
-    img = Image.fromarray(input_image).resize((tw, th), Image.LANCZOS if k > 1 else Image.BOX)
-    return np.asarray(img)
+    if not torch.cuda.is_available():
+        raise RuntimeError("resize_image runs on the MI355X only (no CPU path)")
+    from . import imageproc, ops
+    src = ops.h2d(torch.from_numpy(np.ascontiguousarray(input_image))[None], torch.device("cuda", torch.cuda.current_device()))
+    return imageproc.cv_resize_u8(src, th, tw, "lanczos4" if k > 1 else "area")[0].cpu().numpy()
 
 
 class CannyDetector:

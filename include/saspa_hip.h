@@ -51,6 +51,7 @@ extern "C" {
 #define SASPA_GEMM_AUTO 0
 #define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
 #define SASPA_GEMM_WIDE 2  /* 8-wave 256x320 / 256x256 tile, one workgroup per CU */
+#define SASPA_GEMM_WS 3    /* wave-specialised 128x160 tile (4 MMA waves + 4 loader / epilogue waves): short-K bf16 layers */
 
 #define SASPA_KORDER_TAP 0
 #define SASPA_KORDER_CHUNK 1

@@ -10,3 +10,6 @@ __attribute__((visibility("hidden"))) int saspa_gemm_pp_launch(const SaspaGemmPa
 __attribute__((visibility("hidden"))) bool saspa_gemm_pp_eligible(const SaspaGemmParams& p);
 // split-K reduce + epilogue launch shared by both variants (saspa_gemm.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit);
+// wave-specialised 8-wave kernel for short-K bf16 layers (saspa_gemm_ws.hip)
+__attribute__((visibility("hidden"))) int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s);
+__attribute__((visibility("hidden"))) bool saspa_gemm_ws_eligible(const SaspaGemmParams& p);

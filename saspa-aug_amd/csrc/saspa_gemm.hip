@@ -879,7 +879,20 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const long long nb = (long long)p.nb1 * p.nb2;
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
   const bool n160 = (p.N % 160) == 0;
-  if (p.act == SASPA_ACT_GEGLU) return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
+  if constexpr (sizeof(T) == 2) {
+    if (p.variant == SASPA_GEMM_WS) return saspa_gemm_ws_launch(p, s);
+  } else {
+    if (p.variant == SASPA_GEMM_WS) return SASPA_ERANGE;
+  }
+  if (p.act == SASPA_ACT_GEGLU) {
+    if constexpr (sizeof(T) == 2) {
+      // level-0 projection (K = 320): 199 vs 214 us on the wave-specialised kernel; K >= 640 is faster on the 4-wave tiles
+      static const bool ws_on_g = !(getenv("SASPA_GEMM_WS") && atoi(getenv("SASPA_GEMM_WS")) == 0);
+      const long long t = (long long)((p.M + 127) / 128) * (p.N / (n160 ? 160 : 128));
+      if (ws_on_g && p.variant == SASPA_GEMM_AUTO && nb == 1 && t >= 256 && p.K <= 384 && saspa_gemm_ws_eligible(p)) return saspa_gemm_ws_launch(p, s);
+    }
+    return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
+  }
   static const int force_tile = getenv("SASPA_GEMM_TILE") ? atoi(getenv("SASPA_GEMM_TILE")) : 0;   // tuning knob
   if (force_tile == 845) return launch<T, 4, 5, 4, 2>(p, s, ksplit);   // 256x160, 8 waves
   if (force_tile == 45) return launch<T, 4, 5>(p, s, ksplit);
@@ -914,6 +927,19 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
     if (p.variant == SASPA_GEMM_WIDE) return SASPA_ERANGE;
   }
   const int bn = n160 ? 160 : 128;
+  if constexpr (sizeof(T) == 2) {
+    // exactly one wave of 128-row tiles (256 <= tiles < 512: the 16x16-level linears, where the 2-workgroups-per-CU kernel
+    // runs half empty) and no K slices: the wave-specialised kernel (saspa_gemm_ws.hip) -- 19 vs 24 us at (4096, 1280,
+    // 1280), 52 vs 72 us at (4096, 1280, 5120); with more tiles it only ties the 4-wave kernel (both sit at the L2 -> LDS
+    // fill rate of a 128x160 tile, tools/ws_stamps.py) and, owning the CU's whole LDS, it keeps the other graph branch's
+    // kernels off the CU (bench 6.07 vs 6.14 images/s when used everywhere).  SASPA_GEMM_WS=0 turns it off (A/B knob).
+    static const bool ws_on = !(getenv("SASPA_GEMM_WS") && atoi(getenv("SASPA_GEMM_WS")) == 0);
+    static const int ws_max = getenv("SASPA_GEMM_WS_MAXTILES") ? atoi(getenv("SASPA_GEMM_WS_MAXTILES")) : 512;
+    if (ws_on && p.variant == SASPA_GEMM_AUTO && ksplit == 1 && nb == 1 && saspa_gemm_ws_eligible(p)) {
+      const long long t = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+      if (t >= 256 && t < ws_max) return saspa_gemm_ws_launch(p, s);
+    }
+  }
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
   if (tiles >= 160 && p.N > 64) return n160 ? launch<T, 4, 5>(p, s, ksplit) : launch<T, 4, 4>(p, s, ksplit);
   return launch<T, 2, 2>(p, s, ksplit);
@@ -1009,7 +1035,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
     if (p.c0 % bk || p.c1 % bk) return SASPA_ERANGE;
   }
-  if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_WIDE) return SASPA_EINVAL;
+  if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_WS) return SASPA_EINVAL;
   if (p.act == SASPA_ACT_GEGLU) {
     // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)
     const int bn = (p.N % 160) == 0 ? 160 : 128;

@@ -17,7 +17,7 @@ ACT_GELU = 4        # saspa_activation only: erf GELU (BERT / Q-Former)
 ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
 ACT_RELU = 5        # saspa_gemm / saspa_activation: ReLU (before the residual add)
 ACT_ADD_RELU = 6    # saspa_gemm only: ReLU AFTER the residual add (ResNet bottleneck)
-GEMM_AUTO, GEMM_TILED, GEMM_WIDE = 0, 1, 2   # SaspaGemmParams.variant
+GEMM_AUTO, GEMM_TILED, GEMM_WIDE, GEMM_WS = 0, 1, 2, 3   # SaspaGemmParams.variant
 
 
 # Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)

@@ -22,7 +22,7 @@ for (M, N, K) in shapes:
     bias = torch.randn(N, device=dev)
     outs = [torch.empty(M, N, device=dev, dtype=BF) for _ in range(4)]
     i = [0]; row = []
-    for (name, variant) in (("auto", 0), ("tiled", 1), ("wide", 2)):
+    for (name, variant) in (("auto", 0), ("tiled", 1), ("wide", 2), ("ws", 3)):
         def f():
             j = i[0] % 4; i[0] += 1
             ops.linear(xs[j], wt, bias, out=outs[j], variant=variant, ksplit=1)

@@ -265,6 +265,12 @@ int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, 
                         int n_special, const double* concept_w, int n_concepts, double threshold, uint8_t* images,
                         long long bytes_per_image, int* flags, void* stream);
 
+/* SDEdit / img2img start latents (StableDiffusionControlNetImg2ImgPipeline.prepare_latents): per 8-channel
+ * latent pixel, moments = AutoencoderKL.encode's quant_conv output (mean | logvar), e1 / e2 = the two generator draws:
+ * out = sa * ((mean + exp(0.5 * clamp(logvar, -30, 20)) * e1) * scaling) + s1m * e2, pad channels zero. */
+int saspa_vae_sample_noise(int dtype, const void* moments, const void* e1, const void* e2, void* out, long long npix,
+                           float scaling, float sa, float s1m, void* stream);
+
 /* ---- filter stage (all_utils/utils.py:306-323, :357-375) ----------------------------------------------
  * 2-D pooling over channels-last activations [batch][hin][win][C] -> [batch][hout][wout][C], hout = (hin + 2*pad - k) /
  * stride + 1: mode 0 = max (nn.MaxPool2d(3, 2, 1) of the ResNet stem: padding never wins), mode 1 = average over the k*k

@@ -148,6 +148,40 @@ def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents,
     return out
 
 
+@torch.no_grad()
+def sd_controlnet_img2img_pipeline(weights, cfgs, ids_pos, ids_neg, source_u8, control_u8, sample_noise, noise, steps, strength,
+                                   guidance_scale=7.5, conditioning_scale=0.75, return_latents=False):
+    """StableDiffusionControlNetImg2ImgPipeline.__call__ as the reference invokes it with SDEDIT = 1
+    (run_aug/run_aug.py:203-206, :252-260, :274-276; [upstream] diffusers 0.32.2): the source image (VaeImageProcessor:
+    [-1, 1]) is encoded, latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * sample_noise) * scaling_factor, noised to
+    the first kept timestep with `noise` (scheduler.add_noise), then the LAST int(steps * strength) of the `steps` DDIM
+    steps run with CFG + ControlNet.  sample_noise / noise: [1,4,H/8,W/8], the two consecutive draws from the generator."""
+    ctx = M.clip_text_forward(weights["text"], cfgs["text"], torch.cat([ids_neg, ids_pos], 0))
+    cond = prepare_control(control_u8)
+    cond2 = torch.cat([cond, cond], 0)
+    src = torch.from_numpy(np.ascontiguousarray(source_u8)).float().permute(2, 0, 1)[None] / 127.5 - 1.0
+    mean, logvar = M.vae_encode(weights["vae"], cfgs["vae"], src)
+    std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+    x0 = (mean + std * sample_noise.float()) * cfgs["vae"]["scaling_factor"]
+    sch = DDIM()
+    ts_all = sch.set_timesteps(steps)
+    init = min(int(steps * strength), steps)
+    ts = ts_all[max(steps - init, 0):]
+    a_t = sch.alphas_cumprod[int(ts[0])]
+    x = a_t ** 0.5 * x0 + (1 - a_t) ** 0.5 * noise.float()
+    for t in ts:
+        x2 = torch.cat([x, x], 0)
+        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x2, int(t), ctx, cond2, conditioning_scale)
+        eps2 = M.unet_forward(weights["unet"], cfgs["unet"], x2, int(t), ctx, down, mid)
+        eps_u, eps_c = eps2.chunk(2)
+        x = sch.step(eps_u + guidance_scale * (eps_c - eps_u), t, x)
+    img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
+    out = postprocess(img)
+    if return_latents:
+        return out, x, img
+    return out
+
+
 def run_safety_checker(sd, cfg, images_u8):
     """StableDiffusionControlNetPipeline.run_safety_checker + the checker's black-out: u8 [B,H,W,3] ->
     (u8 images with flagged ones zeroed, flags)."""
@@ -197,26 +231,44 @@ def blip_controlnet_pipeline(weights, cfgs, ids_prompt, ids_neg, query_embeds, c
 
 @torch.no_grad()
 def sdxl_controlnet_pipeline(weights, cfgs, ids1, ids2, control_u8, latents, steps, conditioning_scale=0.75,
-                             return_latents=False):
+                             return_latents=False, guidance_scale=0.0, neg_ids1=None, neg_ids2=None):
     """StableDiffusionXLControlNetPipeline.__call__ as the reference invokes it for sd_xl-turbo
     (run_aug/run_aug.py:189-201, :223-228, :564-571): guidance_scale 0 -> NO classifier-free guidance (one
     conditional evaluation per step, no negative prompt), 2 steps, DDIMScheduler.from_config(<SDXL-Turbo scheduler
     config>) -> "trailing" timesteps, set_alpha_to_one=False, clip_sample=False; conditioning scale 0.75 (:269);
     VAE = sdxl-vae-fp16-fix upcast to fp32, scaling factor 0.13025.
     ids1 / ids2: int64 [1,77] from tokenizer (EOS-padded) / tokenizer_2 (0-padded).  Prompt embedding = concat of the
-    two towers' hidden_states[-2]; pooled = text_encoder_2's projected EOS state; add_time_ids = (H, W, 0, 0, H, W)."""
+    two towers' hidden_states[-2]; pooled = text_encoder_2's projected EOS state; add_time_ids = (H, W, 0, 0, H, W).
+    guidance_scale > 1 (BASELINE configs[4] family): CFG, uncond half first; without a negative prompt the negative
+    embeddings are zeros (force_zeros_for_empty_prompt of the sdxl-turbo repo)."""
     h1, _ = M.clip_text_forward(weights["text"], cfgs["text"], ids1, penultimate=True)
     h2, pooled = M.clip_text_forward(weights["text2"], cfgs["text2"], ids2, penultimate=True)
     ctx = torch.cat([h1, h2], dim=-1)
     hh, ww = control_u8.shape[:2]
-    added = dict(text_embeds=pooled, time_ids=torch.tensor([[hh, ww, 0, 0, hh, ww]], dtype=torch.float32))
+    cfg = guidance_scale > 1.0
     cond = prepare_control(control_u8)
+    if cfg:
+        if neg_ids1 is None:
+            nctx, npooled = torch.zeros_like(ctx), torch.zeros_like(pooled)
+        else:
+            n1, _ = M.clip_text_forward(weights["text"], cfgs["text"], neg_ids1, penultimate=True)
+            n2, npooled = M.clip_text_forward(weights["text2"], cfgs["text2"], neg_ids2, penultimate=True)
+            nctx = torch.cat([n1, n2], dim=-1)
+        ctx = torch.cat([nctx, ctx], 0)
+        pooled = torch.cat([npooled, pooled], 0)
+        cond = torch.cat([cond, cond], 0)
+    nb = ctx.shape[0]
+    added = dict(text_embeds=pooled, time_ids=torch.tensor([[hh, ww, 0, 0, hh, ww]] * nb, dtype=torch.float32))
     sch = DDIM(spacing="trailing")
     x = latents.clone().float() * sch.init_noise_sigma
     for t in sch.set_timesteps(steps):
-        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], x, int(t), ctx, cond,
+        xin = torch.cat([x, x], 0) if cfg else x
+        down, mid = M.controlnet_forward(weights["controlnet"], cfgs["controlnet"], xin, int(t), ctx, cond,
                                          conditioning_scale, added)
-        eps = M.unet_forward(weights["unet"], cfgs["unet"], x, int(t), ctx, down, mid, added)
+        eps = M.unet_forward(weights["unet"], cfgs["unet"], xin, int(t), ctx, down, mid, added)
+        if cfg:
+            eps_u, eps_c = eps.chunk(2)
+            eps = eps_u + guidance_scale * (eps_c - eps_u)
         x = sch.step(eps, t, x)
     img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
     out = postprocess(img)

@@ -294,6 +294,28 @@ def vae_decode(sd, cfg, z):
     return conv2d(sd, "decoder.conv_out", h)
 
 
+def vae_encode(sd, cfg, x):
+    """AutoencoderKL.encode(x).latent_dist parameters: x [B,3,H,W] in [-1,1] -> (mean, logvar) [B,4,H/8,W/8] each
+    (Encoder: conv_in, 4 down blocks of 2 resnets + Downsample2D(padding=0: F.pad (0,1,0,1) then stride-2 conv) on the first
+    three, mid block with one single-head attention, GroupNorm + SiLU, conv_out to 2*latent channels; quant_conv)."""
+    g = cfg["groups"]
+    h = conv2d(sd, "encoder.conv_in", x)
+    n_lvl = len(cfg["block_out"])
+    for i in range(n_lvl):
+        for j in range(cfg["layers"]):
+            h = resnet_block(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, None, g, 1e-6)
+        if i != n_lvl - 1:
+            h = F.pad(h, (0, 1, 0, 1))
+            h = conv2d(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=0)
+    h = resnet_block(sd, "encoder.mid_block.resnets.0", h, None, g, 1e-6)
+    h = vae_mid_attention(sd, "encoder.mid_block.attentions.0", h, g)
+    h = resnet_block(sd, "encoder.mid_block.resnets.1", h, None, g, 1e-6)
+    h = F.silu(group_norm(sd, "encoder.conv_norm_out", h, g, 1e-6))
+    h = conv2d(sd, "encoder.conv_out", h)
+    moments = conv2d(sd, "quant_conv", h, padding=0)
+    return moments.chunk(2, dim=1)
+
+
 # --------------------------------------------------------------------------
 # CLIP text tower (last_hidden_state after final LN; causal mask; quick-GELU)
 # --------------------------------------------------------------------------

@@ -78,6 +78,7 @@ SYMBOLS = {
     "saspa_signsqrt_l2norm": (_I, [_P, _LL, _P, _LL, _I, _LL, _F, _F, _P]),
     "saspa_resize_taps_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "saspa_resize_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "saspa_vae_sample_noise": (_I, [_I, _P, _P, _P, _P, _LL, _F, _F, _F, _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

@@ -405,6 +405,44 @@ extern "C" int saspa_ddim_step_dev(int dtype, const void* eps, void* x, int nimg
   return 0;
 }
 
+// img2img start latents (SDEdit): one 8-channel pixel per lane.  moments = quant_conv output (mean in channels 0..3, logvar
+// in 4..7); x0 = (mean + exp(0.5 * clamp(logvar, -30, 20)) * e1) * scaling; out = sa * x0 + s1m * e2 (scheduler.add_noise)
+template <typename T>
+__global__ __launch_bounds__(256) void vae_sample_noise_kernel(const T* mom, const T* e1, const T* e2, T* out, long long npix,
+                                                               float scaling, float sa, float s1m) {
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < npix; it += (long long)gridDim.x * 256) {
+    float m[8], a[8], b[8], o[8];
+    load8(mom + it * 8, m);
+    load8(e1 + it * 8, a);
+    load8(e2 + it * 8, b);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float lv = fminf(fmaxf(m[4 + c], -30.0f), 20.0f);
+      const float x0 = (m[c] + expf(0.5f * lv) * a[c]) * scaling;
+      o[c] = sa * x0 + s1m * b[c];
+      o[4 + c] = 0.0f;
+    }
+    store8(out + it * 8, o);
+  }
+}
+
+extern "C" int saspa_vae_sample_noise(int dtype, const void* moments, const void* e1, const void* e2, void* out, long long npix,
+                                      float scaling, float sa, float s1m, void* stream) {
+  if (!moments || !e1 || !e2 || !out || npix <= 0) return SASPA_EINVAL;
+  if (!aligned16(moments) || !aligned16(e1) || !aligned16(e2) || !aligned16(out)) return SASPA_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(vae_sample_noise_kernel<bf16_t>, dim3(grid_for(npix)), dim3(256), 0, s, (const bf16_t*)moments, (const bf16_t*)e1,
+                       (const bf16_t*)e2, (bf16_t*)out, npix, scaling, sa, s1m);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(vae_sample_noise_kernel<float>, dim3(grid_for(npix)), dim3(256), 0, s, (const float*)moments, (const float*)e1,
+                       (const float*)e2, (float*)out, npix, scaling, sa, s1m);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int saspa_scale(int dtype, const void* x, void* y, long long n, float sc, void* stream) {
   if (!x || !y || n <= 0) return SASPA_EINVAL;
   if (n % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;

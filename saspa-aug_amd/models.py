@@ -488,8 +488,10 @@ class VAEDecoder:
         return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
 
     def mid_attention(self, x):
+        return self._mid_attention(x, "decoder.mid_block.attentions.0")
+
+    def _mid_attention(self, x, a):
         p = self.p
-        a = "decoder.mid_block.attentions.0"
         b, hh, ww, c = x.shape
         n = hh * ww
         h = ops.groupnorm(x, p[a + ".group_norm.g"], p[a + ".group_norm.b"], self.cfg["groups"], 1e-6).view(b, n, c)
@@ -526,6 +528,51 @@ class VAEDecoder:
                 h = ops.conv(h, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True)
         h = ops.groupnorm(h, p["decoder.conv_norm_out.g"], p["decoder.conv_norm_out.b"], cfg["groups"], 1e-6, SILU)
         return ops.conv(h, p["decoder.conv_out.w"], p["decoder.conv_out.b"], kh=3, kw=3, pad=1)
+
+
+class VAEEncoder(VAEDecoder):
+    """AutoencoderKL.encode up to the latent distribution's parameters (SDEdit / img2img): conv_in, down
+    blocks (2 resnets + a stride-2 conv that zero-pads right / bottom only), mid block (resnet, single-head attention,
+    resnet), GroupNorm + SiLU, conv_out, quant_conv -> [B,h,w,8] = mean (channels 0..3) | logvar (4..7)."""
+
+    def __init__(self, sd, cfg, dev, dtype):
+        self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        pk = self.pk = _Packed(sd, dev, dtype)
+        self.p = pk.p
+        pk.conv("encoder.conv_in")
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"]):
+                self._pack_resnet(f"encoder.down_blocks.{i}.resnets.{j}")
+            if i != n_lvl - 1:
+                pk.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv")
+        self._pack_resnet("encoder.mid_block.resnets.0")
+        a = "encoder.mid_block.attentions.0"
+        pk.norm(a + ".group_norm")
+        pk.attn(a, True, has_bias=True)
+        self._pack_resnet("encoder.mid_block.resnets.1")
+        pk.norm("encoder.conv_norm_out")
+        pk.conv("encoder.conv_out")
+        pk.conv("quant_conv")
+        pk.sd = None
+
+    def encode(self, x):
+        """x: [B,H,W,8] pixels in [-1,1] (3 live channels) -> moments [B,H/8,W/8,8]."""
+        p, cfg = self.p, self.cfg
+        h = ops.conv(x, p["encoder.conv_in.w"], p["encoder.conv_in.b"], kh=3, kw=3, pad=1)
+        n_lvl = len(cfg["block_out"])
+        for i in range(n_lvl):
+            for j in range(cfg["layers"]):
+                h = self.resnet(f"encoder.down_blocks.{i}.resnets.{j}", h)
+            if i != n_lvl - 1:
+                d = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                h = ops.conv(h, p[d + ".w"], p[d + ".b"], kh=3, kw=3, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2))
+        h = self.resnet("encoder.mid_block.resnets.0", h)
+        h = self._mid_attention(h, "encoder.mid_block.attentions.0")
+        h = self.resnet("encoder.mid_block.resnets.1", h)
+        h = ops.groupnorm(h, p["encoder.conv_norm_out.g"], p["encoder.conv_norm_out.b"], cfg["groups"], 1e-6, SILU)
+        h = ops.conv(h, p["encoder.conv_out.w"], p["encoder.conv_out.b"], kh=3, kw=3, pad=1)
+        return ops.conv(h, p["quant_conv.w"], p["quant_conv.b"])
 
 
 class CLIPText:

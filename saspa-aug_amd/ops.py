@@ -104,7 +104,7 @@ def _set_splitk(p, m, n, k, t, force=None):
 
 
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
-         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None):
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None, out_hw=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
     (pad channels zero).  ``korder``: K order the weights were packed in (default: the tensor's
@@ -116,6 +116,10 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     hv, wv = (2 * h, 2 * wd) if upsample else (h, wd)
     ho = (hv + 2 * pad - kh) // stride + 1
     wo = (wv + 2 * pad - kw) // stride + 1
+    if out_hw is not None:
+        # asymmetric zero padding (Downsample2D(padding=0) of the VAE encoder pads right / bottom only): windows may hang
+        # over the far edges, where the loaders' bounds masks read zeros; the C ABI checks the window origins
+        ho, wo = out_hw
     n = w.shape[0] if n_out is None else n_out
     # geometry is validated HERE: the kernel trusts it (a mismatched skip / residual would be read out of bounds)
     if x2 is not None and (tuple(x2.shape[:3]) != (b, h, wd) or x2.dtype != x.dtype):
@@ -463,6 +467,17 @@ def index_add(index, delta=1):
     _check_dev(index)
     _lib.check(_lib.load().saspa_index_add(_ptr(index), int(delta), _stream()), "saspa_index_add")
     return index
+
+
+def vae_sample_noise(moments, e1, e2, scaling, sa, s1m):
+    """moments [B,h,w,8] (mean | logvar), e1 / e2 [B,h,w,8] noise draws -> noised start latents [B,h,w,8] (img2img)."""
+    _check_dev(moments, e1, e2)
+    out = torch.empty_like(moments)
+    npix = moments.numel() // 8
+    _lib.check(_lib.load().saspa_vae_sample_noise(_dt(moments), _ptr(moments.contiguous()), _ptr(e1.contiguous()), _ptr(e2.contiguous()),
+                                                  _ptr(out), npix, float(scaling), float(sa), float(s1m), _stream()),
+               "saspa_vae_sample_noise")
+    return out
 
 
 def scale(x, s, out=None):

@@ -282,17 +282,20 @@ class StableDiffusionControlNetPipeline:
     def _positive_context(self, prompt_ids, query_embeds=None):
         return self.encode_prompts(prompt_ids)
 
-    def _sample(self, x2, b, hw, ctx, cemb2, steps, guidance_scale, cscale):
-        """The denoising loop on the CFG-doubled latents x2 [2B,h,w,8] (in place)."""
+    def _sample(self, x2, b, hw, ctx, cemb2, steps, guidance_scale, cscale, t_start=0):
+        """The denoising loop on the CFG-doubled latents x2 [2B,h,w,8] (in place).  t_start > 0 (img2img / SDEdit): only the
+        timesteps from index t_start of the `steps`-step schedule run (DDIM only)."""
         sch = self.scheduler
         nc = self.cfgs["unet"]["out_channels"]
+        if t_start and isinstance(sch, PNDMScheduler):
+            raise NotImplementedError("img2img runs on DDIM / UniPC (the reference switches non-BLIP pipelines away from PNDM)")
         if graphs_enabled():
             if isinstance(sch, PNDMScheduler):
                 plan = sch.plan(steps)                 # N+1 evaluations, the second timestep twice
                 ts, plan = [t for t, _ in plan], [d for _, d in plan]
             else:
-                ts, plan = sch.set_timesteps(steps), None
-            x2.copy_(self._step_graph(x2, cemb2, ctx, steps, True, guidance_scale, cscale, ts).run_on(x2, cemb2, ctx, ts, plan=plan))
+                ts, plan = list(sch.set_timesteps(steps))[t_start:], None
+            x2.copy_(self._step_graph(x2, cemb2, ctx, len(ts) if t_start else steps, True, guidance_scale, cscale, ts).run_on(x2, cemb2, ctx, ts, plan=plan))
             return
         self.unet.prepare_context(ctx)
         self.controlnet.prepare_context(ctx)
@@ -317,7 +320,7 @@ class StableDiffusionControlNetPipeline:
                 ops.cfg_plms_step(eps, x2, hist, saved if d["use_saved"] else None, b, hw, nc, guidance_scale,
                                   d["store_slot"], d["w_cur"], d["w_hist"], d["coef_sample"], d["coef_model"])
         else:
-            ts = sch.set_timesteps(steps)
+            ts = list(sch.set_timesteps(steps))[t_start:]
             self.unet.prepare_timesteps(ts)
             self.controlnet.prepare_timesteps(ts)
             for i, t in enumerate(ts):
@@ -401,6 +404,94 @@ class StableDiffusionControlNetPipeline:
         arr = out.cpu().numpy()
         nsfw = None if self.last_nsfw is None else [bool(v) for v in self.last_nsfw.cpu().tolist()]
         return PipelineOutput([Image.fromarray(a) for a in arr], nsfw)
+
+
+class StableDiffusionControlNetImg2ImgPipeline(StableDiffusionControlNetPipeline):
+    """Drop-in for diffusers' `StableDiffusionControlNetImg2ImgPipeline` as the reference builds it with SDEDIT = 1
+    (run_aug/run_aug.py:203-206) and calls it (:252-260, :274-276): `pipe(prompt, image=<source PIL>, control_image=<canny
+    PIL>, strength, num_inference_steps, generator, guidance_scale, negative_prompt, controlnet_conditioning_scale)`.
+    The source image is encoded by the VAE encoder (HIP launch graph), the latent is sampled from the posterior and noised
+    to the first kept timestep in one kernel (`saspa_vae_sample_noise`; the two noise draws come from the CPU generator in
+    the reference's order: posterior sample first, then the scheduler noise), and the last int(steps * strength) DDIM steps
+    run exactly like the text-to-image loop (same captured step graph)."""
+
+    def _build_extra(self, sd, cf, device, cdt):
+        super()._build_extra(sd, cf, device, cdt)
+        if "encoder.conv_in.weight" not in sd["vae"]:
+            raise KeyError("the VAE checkpoint has no encoder half: img2img (SDEdit) needs vae/encoder.* and quant_conv")
+        self.vae_encoder = models.VAEEncoder(sd["vae"], cf["vae"], device, cdt)
+
+    @staticmethod
+    def kept_steps(num_inference_steps, strength):
+        """get_timesteps: (index of the first kept timestep, number of kept steps)."""
+        init = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init, 0)
+        return t_start, num_inference_steps - t_start
+
+    @torch.no_grad()
+    def generate_batch_img2img(self, prompt_ids, negative_ids, source_u8, control_u8, sample_noise, noise, num_inference_steps,
+                               strength, guidance_scale=7.5, controlnet_conditioning_scale=0.75, return_latents=False):
+        """source_u8 / control_u8: u8 [B,H,W,3] (numpy or device); sample_noise / noise: [B,4,H/8,W/8] CPU draws."""
+        self._need_device()
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("guidance_scale <= 1 (no CFG) belongs to the SDXL-Turbo branch")
+        if not 0.0 <= strength <= 1.0:
+            raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
+        t_start, kept = self.kept_steps(num_inference_steps, strength)
+        if kept < 1:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of pipeline "
+                             f"steps is {kept} which is < 1 and not appropriate for this pipeline.")
+        dev, dt = self.device, self.dtype
+        to_dev = lambda a: ops.h2d(a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)), dev).contiguous()   # noqa: E731
+        src, ctrl = to_dev(source_u8), to_dev(control_u8)
+        b, hh, ww, _ = ctrl.shape
+        if tuple(src.shape) != tuple(ctrl.shape):
+            raise ValueError("source and control images must have the same size")
+        mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
+        if hh % mult or ww % mult:
+            raise ValueError(f"image sides must be multiples of {mult} (got {hh}x{ww})")
+        from . import imageproc
+        px = imageproc.normalize_u8(src, dt, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))          # VaeImageProcessor: [0,255] -> [-1,1]
+        moments = self.vae_encoder.encode(px)
+        sch = self.scheduler
+        ts = list(sch.set_timesteps(num_inference_steps))
+        a_t = float(sch.alphas_cumprod[int(ts[t_start])])
+        x = ops.vae_sample_noise(moments, self.latents_to_device(sample_noise), self.latents_to_device(noise),
+                                 self.cfgs["vae"]["scaling_factor"], a_t ** 0.5, (1.0 - a_t) ** 0.5)
+        pos = self._positive_context(prompt_ids)
+        neg = self._negative_context(negative_ids)
+        if neg.shape[0] == 1 and b > 1:
+            neg = neg.expand(b, -1, -1)
+        ctx = torch.cat([neg, pos], 0).contiguous()
+        cemb = self.controlnet.cond_embedding(ops.u8_to_act(ctrl, dt))
+        x2 = torch.cat([x, x], 0).contiguous()
+        self._sample(x2, b, (hh // 8) * (ww // 8), ctx, torch.cat([cemb, cemb], 0), num_inference_steps, guidance_scale,
+                     controlnet_conditioning_scale, t_start=t_start)
+        img = self.vae.decode(ops.scale(x2[:b], 1.0 / self.cfgs["vae"]["scaling_factor"]))
+        out, self.last_nsfw = self.run_safety_checker(ops.act_to_u8(img))
+        if return_latents:
+            return out, x2[:b], img
+        return out
+
+    def __call__(self, prompt=None, image=None, control_image=None, strength=0.8, num_inference_steps=50, generator=None,
+                 guidance_scale=7.5, negative_prompt=None, controlnet_conditioning_scale=0.8, **unused):
+        self._need_device()
+        if image is None or control_image is None or prompt is None:
+            raise ValueError("`prompt`, `image` (the source image) and `control_image` are required")
+        as_u8 = lambda im: np.asarray(im.convert("RGB") if isinstance(im, Image.Image) else im, dtype=np.uint8)   # noqa: E731
+        src, ctrl = as_u8(image), as_u8(control_image)
+        hh, ww = ctrl.shape[:2]
+        if generator is not None and generator.device.type != "cpu":
+            raise NotImplementedError("the reference passes the global CPU generator (run_aug/run_aug.py:324)")
+        shape = (1, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
+        e1 = torch.randn(shape, generator=generator, dtype=self.noise_dtype)             # latent_dist.sample(generator)
+        e2 = torch.randn(shape, generator=generator, dtype=self.noise_dtype)             # randn_tensor for add_noise
+        ids = self.tokenizer(str(prompt))
+        neg = self.tokenizer(negative_prompt if negative_prompt is not None else "")
+        out = self.generate_batch_img2img(ids, neg, src[None], ctrl[None], e1, e2, num_inference_steps, strength, guidance_scale,
+                                          controlnet_conditioning_scale)
+        nsfw = None if self.last_nsfw is None else [bool(v) for v in self.last_nsfw.cpu().tolist()]
+        return PipelineOutput([Image.fromarray(a) for a in out.cpu().numpy()], nsfw)
 
 
 class BlipDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
@@ -590,13 +681,13 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
     @torch.no_grad()
     def generate_batch(self, prompt_ids, negative_ids, control_u8, latents, num_inference_steps, guidance_scale=0.0,
                        controlnet_conditioning_scale=0.75, return_latents=False, latents_on_device=False,
-                       prompt_ids_2=None, **unused):
-        """Same contract as the SD-1.5 form; `negative_ids` is ignored (no CFG at the reference's operating point) and
-        `prompt_ids_2` defaults to the tokenizer_2 padding of `prompt_ids`."""
+                       prompt_ids_2=None, negative_ids_2=None, **unused):
+        """Same contract as the SD-1.5 form.  guidance_scale <= 1 (the reference's sd_xl-turbo operating point,
+        run_aug/run_aug.py:568): no CFG, `negative_ids` ignored.  guidance_scale > 1: classifier-free guidance with the
+        negative prompt (None -> zero embeddings).  `prompt_ids_2` / `negative_ids_2` default to the tokenizer_2 padding
+        of the first tokenizer's ids."""
         self._need_device()
-        if guidance_scale > 1.0:
-            raise NotImplementedError("the reference runs sd_xl-turbo with guidance_scale 0 (run_aug/run_aug.py:568); "
-                                      "CFG for SDXL is not built")
+        cfg = guidance_scale > 1.0                         # diffusers: do_classifier_free_guidance = guidance_scale > 1
         dev, dt = self.device, self.dtype
         ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
         ctrl = ops.h2d(ctrl, dev).contiguous()
@@ -612,14 +703,32 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         ids1 = np.asarray(prompt_ids.cpu() if torch.is_tensor(prompt_ids) else prompt_ids)
         ids2 = self.pad_ids_2(ids1) if prompt_ids_2 is None else prompt_ids_2
         ctx, pooled = self.encode_prompts_xl(ids1, ids2)
-        time_ids = [[hh, ww, 0, 0, hh, ww]] * b            # original_size + crops_coords_top_left + target_size
+        if cfg:
+            # BASELINE configs[4] family (guidance on): uncond first.  negative_prompt None -> ZERO embeddings (sdxl-turbo's
+            # model_index.json has force_zeros_for_empty_prompt = true), otherwise both towers encode the negative prompt
+            if negative_ids is None:
+                nctx, npooled = torch.zeros_like(ctx), torch.zeros_like(pooled)
+            else:
+                n1 = np.asarray(negative_ids.cpu() if torch.is_tensor(negative_ids) else negative_ids)
+                n2 = self.pad_ids_2(n1) if negative_ids_2 is None else negative_ids_2
+                nctx, npooled = self.encode_prompts_xl(n1, n2)
+                if nctx.shape[0] == 1 and b > 1:
+                    nctx, npooled = nctx.expand(b, -1, -1), npooled.expand(b, -1)
+            ctx = torch.cat([nctx, ctx], 0).contiguous()
+            pooled = torch.cat([npooled, pooled], 0).contiguous()
+        nb = 2 * b if cfg else b
+        time_ids = [[hh, ww, 0, 0, hh, ww]] * nb           # original_size + crops_coords_top_left + target_size
         cond = ops.u8_to_act(ctrl, dt)
         cemb = self.controlnet.cond_embedding(cond)
         x = (latents if latents_on_device else self.latents_to_device(latents)).contiguous()
+        if cfg:
+            x = torch.cat([x, x], 0).contiguous()
+            cemb = torch.cat([cemb, cemb], 0)
         sch = self.scheduler
         ts = sch.set_timesteps(num_inference_steps)
         if graphs_enabled():
-            g = self._step_graph(x, cemb, ctx, num_inference_steps, False, 0.0, controlnet_conditioning_scale, ts)
+            g = self._step_graph(x, cemb, ctx, num_inference_steps, cfg, float(guidance_scale) if cfg else 0.0,
+                                 controlnet_conditioning_scale, ts)
             x = g.run_on(x, cemb, ctx, ts, (pooled, time_ids)).clone()
         else:
             for net in (self.unet, self.controlnet):
@@ -631,7 +740,11 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
                 mid, skips = self.unet.encode(x, i)
                 skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
                 self.unet.decode(mid2, skips2, i, out=eps)
-                ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))
+                if cfg:
+                    ops.cfg_ddim_step(eps, x, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
+                else:
+                    ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))
+        x = x[:b].contiguous() if cfg else x
         z = ops.scale(x, 1.0 / self.cfgs["vae"]["scaling_factor"])
         if self.vae.dtype != z.dtype:
             z = z.to(self.vae.dtype)                      # upcast_vae(): latents follow the VAE dtype
@@ -655,7 +768,11 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         lat = torch.randn((1, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8), generator=generator, dtype=self.noise_dtype)
         ids1 = self.tokenizer(str(prompt))
         ids2 = self.pad_ids_2(self.tokenizer_2(str(prompt)))
-        out = self.generate_batch(ids1, None, ctrl[None], lat, num_inference_steps, guidance_scale,
-                                  controlnet_conditioning_scale, prompt_ids_2=ids2)
+        n1 = n2 = None
+        if negative_prompt is not None and guidance_scale > 1.0:
+            n1 = self.tokenizer(str(negative_prompt))
+            n2 = self.pad_ids_2(self.tokenizer_2(str(negative_prompt)))
+        out = self.generate_batch(ids1, n1, ctrl[None], lat, num_inference_steps, guidance_scale,
+                                  controlnet_conditioning_scale, prompt_ids_2=ids2, negative_ids_2=n2)
         arr = out.cpu().numpy()
         return PipelineOutput([Image.fromarray(a) for a in arr], None)

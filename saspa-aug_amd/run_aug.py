@@ -250,19 +250,23 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
         pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
         pipe.upcast_vae()
         return pipe
-    if base_model != "sd_v1.5" or controlnet != "canny" or SDEdit:
+    if base_model != "sd_v1.5" or controlnet != "canny":
         raise NotImplementedError(
-            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5, blip_diffusion and sd_xl-turbo with the canny ControlNet "
-            "are built; SDEdit / HED / ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are baseline branches")
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 (text-to-image and SDEdit img2img), blip_diffusion and "
+            "sd_xl-turbo with the canny ControlNet are built; HED / ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are baseline branches")
     cfgs = cfgs or SD15
+    if SDEdit:                                  # run_aug/run_aug.py:203-206: StableDiffusionControlNetImg2ImgPipeline
+        from .pipeline import StableDiffusionControlNetImg2ImgPipeline as _Cls
+    else:
+        _Cls = StableDiffusionControlNetPipeline
     if state_dicts is not None:
-        pipe = StableDiffusionControlNetPipeline(state_dicts, cfgs)
+        pipe = _Cls(state_dicts, cfgs)
     elif weights_dir:
-        pipe = StableDiffusionControlNetPipeline.from_pretrained(
+        pipe = _Cls.from_pretrained(
             os.path.join(weights_dir, BASE_MODEL_DICT[base_model]), os.path.join(weights_dir, CONTROLNET_DICT_SD[controlnet]), cfgs)
     else:
         logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
-        pipe = StableDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0)
+        pipe = _Cls.from_synthetic(cfgs, seed=0)
     pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
     return pipe
 
@@ -273,8 +277,8 @@ def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strengt
     """Single-variant call form of the reference (name kept, typo included)."""
     pipe_args = {"prompt": str(prompt), "num_inference_steps": num_inference_steps, "generator": generator,
                  "guidance_scale": guidance_scale, "negative_prompt": negative_prompt}
-    if "ip2p" in base_model or SDEdit or base_model == "blip_diffusion-edit":
-        raise NotImplementedError("only the sd_v1.5 / blip_diffusion + ControlNet call forms are built")
+    if "ip2p" in base_model or base_model == "blip_diffusion-edit" or (SDEdit and control_image is None):
+        raise NotImplementedError("only the ControlNet call forms (text-to-image, SDEdit img2img, BLIP-Diffusion) are built")
     if "blip_diffusion" in base_model:                     # run_aug/run_aug.py:243-250
         pipe_args["reference_image"] = orig_img
         pipe_args["source_subject_category"] = blip_src_category
@@ -284,13 +288,19 @@ def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strengt
         pipe_args["neg_prompt"] = NEGATIVE_PROMPT
         del pipe_args["negative_prompt"]
     if control_image is not None:
-        if "blip_diffusion" in base_model:                 # :262-265 -- note: no conditioning scale is passed
+        if SDEdit:                                         # :252-255 the img2img pipelines name the control image differently
+            pipe_args["control_image"] = control_image
+            pipe_args["controlnet_conditioning_scale"] = control_cond_scale
+        elif "blip_diffusion" in base_model:               # :262-265 -- note: no conditioning scale is passed
             pipe_args["condtioning_image"] = control_image
             pipe_args["height"] = control_image.size[1]
             pipe_args["width"] = control_image.size[0]
         else:
             pipe_args["image"] = control_image
             pipe_args["controlnet_conditioning_scale"] = control_cond_scale
+    if SDEdit:                                             # :274-276
+        pipe_args["image"] = orig_img
+        pipe_args["strength"] = SDEdit_strength
     output = pipe(**pipe_args)
     return output.images[0]
 
@@ -402,9 +412,10 @@ def shard_items(items, world):
     return shards
 
 
-def noise_for_items(items_all, mine, seed, dtype):
+def noise_for_items(items_all, mine, seed, dtype, draws=1):
     """Replays the single sequential CPU noise stream (generator = torch.manual_seed(SEED),
-    run_aug/run_aug.py:324) in work-item order and returns {order: [1,4,h,w]} for `mine`."""
+    run_aug/run_aug.py:324) in work-item order and returns {order: [draws,4,h,w]} for `mine`.  draws = 2 for SDEdit:
+    the img2img pipeline draws the posterior sample and then the scheduler noise for every item."""
     want = {it.order for it in mine}
     last = max(want) if want else -1
     g = torch.manual_seed(seed)
@@ -414,7 +425,7 @@ def noise_for_items(items_all, mine, seed, dtype):
             continue
         if it.order > last:
             break
-        n = torch.randn((1, 4, it.height // 8, it.width // 8), generator=g, dtype=dtype)
+        n = torch.cat([torch.randn((1, 4, it.height // 8, it.width // 8), generator=g, dtype=dtype) for _ in range(draws)])
         if it.order in want:
             out[it.order] = n
     return out
@@ -474,6 +485,11 @@ def hip_batch_generator(pipe, s: Settings):
             q = pipe.get_query_embeddings(refs, [category] * len(batch))
             ids = np.concatenate([tok(pipe.build_prompt(it.prompt, category), max_len=pipe.prompt_token_count()) for it in batch])
             out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE, 1.0, query_embeds=q)
+        elif s.SDEDIT:
+            # SDEdit (run_aug/run_aug.py:252-260, :274-276): img2img from the source image itself, two draws per item
+            ids = np.concatenate([tok(it.prompt) for it in batch])
+            out = pipe.generate_batch_img2img(ids, neg_ids, src, ctrl, lat[0::2], lat[1::2], s.NUM_INFERENCE_STEPS,
+                                              s.SDEDIT_STRENGTH, s.GUIDANCE_SCALE, s.CONTROLNET_CONDITIONING_SCALE)
         else:
             ids = np.concatenate([tok(it.prompt) for it in batch])
             out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
@@ -565,7 +581,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
         noise_dtype = pipe.noise_dtype
     else:
         noise_dtype = torch.float32 if s.PRECISION == "fp32" else torch.float16
-    noises = noise_for_items(items, mine, s.SEED, noise_dtype)        # generator = torch.manual_seed(SEED) (:324)
+    noises = noise_for_items(items, mine, s.SEED, noise_dtype, draws=2 if s.SDEDIT else 1)   # generator = torch.manual_seed(SEED) (:324)
 
     first_variant = {}
     for it in items:

@@ -148,6 +148,33 @@ def vae_decoder_spec(cfg):
     return spec
 
 
+def vae_encoder_spec(cfg):
+    """AutoencoderKL encoder half + quant_conv (same checkpoint file as the decoder; SDEdit / img2img needs it)."""
+    spec = []
+    lc = cfg["latent_channels"]
+    bo = cfg["block_out"]
+    spec += [("encoder.conv_in.weight", (bo[0], cfg["out_channels"], 3, 3), "w"), ("encoder.conv_in.bias", (bo[0],), "bias")]
+    prev = bo[0]
+    for i, c in enumerate(bo):
+        for j in range(cfg["layers"]):
+            _resnet(spec, f"encoder.down_blocks.{i}.resnets.{j}", prev, c, 0)
+            prev = c
+        if i != len(bo) - 1:
+            spec += [(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight", (c, c, 3, 3), "w"),
+                     (f"encoder.down_blocks.{i}.downsamplers.0.conv.bias", (c,), "bias")]
+    top = bo[-1]
+    _resnet(spec, "encoder.mid_block.resnets.0", top, top, 0)
+    a = "encoder.mid_block.attentions.0"
+    spec += [(a + ".group_norm.weight", (top,), "gain"), (a + ".group_norm.bias", (top,), "bias")]
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        spec += [(f"{a}.{n}.weight", (top, top), "w"), (f"{a}.{n}.bias", (top,), "bias")]
+    _resnet(spec, "encoder.mid_block.resnets.1", top, top, 0)
+    spec += [("encoder.conv_norm_out.weight", (top,), "gain"), ("encoder.conv_norm_out.bias", (top,), "bias"),
+             ("encoder.conv_out.weight", (2 * lc, top, 3, 3), "w"), ("encoder.conv_out.bias", (2 * lc,), "bias"),
+             ("quant_conv.weight", (2 * lc, 2 * lc, 1, 1), "w"), ("quant_conv.bias", (2 * lc,), "bias")]
+    return spec
+
+
 def clip_text_spec(cfg):
     w = cfg["width"]
     spec = [("text_model.embeddings.token_embedding.weight", (cfg["vocab"], w), "embed"),
@@ -323,7 +350,7 @@ def wsdan_cal_spec(cfg):
     return spec
 
 
-SPECS.update(clip_rn50=clip_rn50_spec, cal=wsdan_cal_spec)
+SPECS.update(clip_rn50=clip_rn50_spec, cal=wsdan_cal_spec, vae_enc=vae_encoder_spec)
 
 
 def fold_bn(conv_w, sd, bn_pfx, eps=1e-5):
@@ -392,7 +419,11 @@ def synth_state_dict(kind, cfg, seed=0):
 def synth_family(cfgs, seed=0):
     kinds = ("unet", "controlnet", "vae", "text") + (("qformer",) if "qformer" in cfgs else ()) + \
         (("text2",) if "text2" in cfgs else ()) + (("safety",) if "safety" in cfgs else ())
-    return {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
+    fam = {k: synth_state_dict(k, cfgs[k], seed + i) for i, k in enumerate(kinds)}
+    # the checkpoint's vae/ file holds encoder AND decoder: the encoder half (SDEdit / img2img) gets its own seed so the
+    # decoder tensors are unchanged
+    fam["vae"].update(synth_state_dict("vae_enc", cfgs["vae"], seed + 100))
+    return fam
 
 
 _LEGACY_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}

@@ -120,19 +120,24 @@ def test_unet_controlnet_tiny_xl_nonsquare(dev, tiny_xl, dtype):
     assert max(e) < _limits(dtype), e
 
 
-def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg, upcast=True):
+def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg, upcast=True, guidance=0.0, negative=False):
     from oracle.canny import generate_canny_array
     ids1, ids2 = _ids(cfgs, nimg)
+    n1 = n2 = None
+    if negative:
+        n1, n2 = _ids(cfgs, 1, seed=9)
     ctrls = np.stack([generate_canny_array(synthetic_image(hh, ww, 10 + i), 120, 200) for i in range(nimg)])
     g = torch.manual_seed(1)
     lat = torch.cat([torch.randn((1, 4, hh // 8, ww // 8), generator=g, dtype=torch.float32) for _ in range(nimg)])
+    tn = (lambda a: None if a is None else torch.from_numpy(a))
     refs = [OP.sdxl_controlnet_pipeline(fam, cfgs, torch.from_numpy(ids1[i:i + 1]), torch.from_numpy(ids2[i:i + 1]), ctrls[i],
-                                        lat[i:i + 1], steps, return_latents=True) for i in range(nimg)]
+                                        lat[i:i + 1], steps, return_latents=True, guidance_scale=guidance, neg_ids1=tn(n1),
+                                        neg_ids2=tn(n2)) for i in range(nimg)]
     pipe = StableDiffusionXLControlNetPipeline(fam, cfgs)
     if upcast:
         pipe.upcast_vae()
     pipe = pipe.to(dev, dtype)
-    out, x, img = pipe.generate_batch(ids1, None, ctrls, lat, steps, 0.0, 0.75, return_latents=True)
+    out, x, img = pipe.generate_batch(ids1, n1, ctrls, lat, steps, guidance, 0.75, return_latents=True, negative_ids_2=n2)
     ref_u8 = np.concatenate([r[0] for r in refs])
     ref_img = torch.cat([r[2] for r in refs])
     ref_x = torch.cat([r[1] for r in refs])
@@ -150,6 +155,18 @@ def test_sdxl_pipeline_fp32_parity_tiny(dev, tiny_xl):
     assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
     d01, du8, ex, _ = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 128, 4, nimg=1)
     assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_sdxl_pipeline_cfg_fp32_parity_tiny(dev, tiny_xl, negative, monkeypatch):
+    """Classifier-free guidance on the SDXL pipeline (BASELINE configs[4] family: guidance on, 4 steps): uncond half
+    first; no negative prompt -> zero embeddings (force_zeros_for_empty_prompt), else both towers encode it.  fp32 path vs
+    the oracle, graph replay and the Python launch loop."""
+    cfgs, fam = tiny_xl
+    for graph in ("1", "0"):
+        monkeypatch.setenv("SASPA_GRAPH", graph)
+        d01, du8, ex, _ = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 64, 4, nimg=2, guidance=5.0, negative=negative)
+        assert d01 < 1e-3 and du8 <= 1 and ex < 5e-4, (graph, d01, du8, ex)
 
 
 def test_sdxl_pipeline_bf16_with_fp32_vae(dev, tiny_xl):
@@ -191,8 +208,8 @@ def test_sdxl_call_form_and_init_pipeline(dev, tiny_xl):
                             negative_prompt=None, control_image=ctrl)
     b = pipe(generator=torch.manual_seed(1), **kw).images[0]
     assert a.size == (96, 64) and np.array_equal(np.asarray(a), np.asarray(b))
-    with pytest.raises(NotImplementedError):
-        pipe(generator=torch.manual_seed(1), **dict(kw, guidance_scale=5.0))
+    c = pipe(generator=torch.manual_seed(1), **dict(kw, guidance_scale=5.0, negative_prompt="blurry")).images[0]
+    assert c.size == (96, 64) and not np.array_equal(np.asarray(c), np.asarray(b))      # guidance changes the image
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

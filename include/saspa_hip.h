@@ -265,6 +265,14 @@ int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, 
                         int n_special, const double* concept_w, int n_concepts, double threshold, uint8_t* images,
                         long long bytes_per_image, int* flags, void* stream);
 
+/* CFG + one UniPCMultistepScheduler step (run_aug/run_aug.py:218-219 `sampler="unipcmultistep"`): eps, x:
+ * [2*nimg][hw][8]; state: [3][nimg][hw][8] = last sample | newest x0-prediction | the one before (zero-initialised by the
+ * caller).  The 12-float row (saspa_aug_amd/scheduler.py UniPCMultistepScheduler.plan) comes from `row` (host pointer) or,
+ * when `table` is non-NULL, from row *index of a device table (hipGraph replays):
+ *   x0 = (x - r1 * e) * r0;  if r2: x = r3*last + r4*m0 + r5*m1 + r6*x0;  m1, m0, last = m0, x0, x;  x = r7*x + r8*m0 + r9*m1 */
+int saspa_cfg_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc, float guidance,
+                         const float* row, const float* table, const int* index, void* stream);
+
 /* SDEdit / img2img start latents (StableDiffusionControlNetImg2ImgPipeline.prepare_latents): per 8-channel
  * latent pixel, moments = AutoencoderKL.encode's quant_conv output (mean | logvar), e1 / e2 = the two generator draws:
  * out = sa * ((mean + exp(0.5 * clamp(logvar, -30, 20)) * e1) * scaling) + s1m * e2, pad channels zero. */

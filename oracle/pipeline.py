@@ -103,6 +103,91 @@ class PNDM:
         return prev_sample
 
 
+class UniPC:
+    """UniPCMultistepScheduler with the class defaults on the SD-1.5 config (solver_order 2, bh2, predict_x0, epsilon,
+    lower_order_final, leading spacing + steps_offset 1, final sigma zero): a STATEFUL restatement of set_timesteps /
+    step / convert_model_output / multistep_uni_p_bh_update / multistep_uni_c_bh_update ([upstream] diffusers 0.32.2
+    scheduling_unipc_multistep.py, recalled).  The product derives closed-form per-step coefficients instead
+    (saspa_aug_amd.scheduler.UniPCMultistepScheduler.plan); tests compare the two on arbitrary model outputs."""
+
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, solver_order=2, solver_type="bh2"):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train, self.steps_offset, self.order, self.solver_type = num_train, steps_offset, solver_order, solver_type
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n):
+        ratio = self.num_train // (n + 1)
+        ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        ac = self.alphas_cumprod.double().numpy()
+        sig = np.sqrt((1 - ac) / ac)
+        self.sigmas = torch.from_numpy(np.concatenate([np.interp(ts, np.arange(0, len(sig)), sig), [0.0]]))
+        self.timesteps = ts
+        self.model_outputs = [None] * self.order
+        self.lower_order_nums, self.step_index, self.last_sample, self.this_order = 0, 0, None, 1
+        return ts
+
+    @staticmethod
+    def _as(sigma):
+        alpha_t = 1 / (sigma ** 2 + 1) ** 0.5
+        return alpha_t, sigma * alpha_t
+
+    def _update(self, x, m0, older, sig_t, sig_s0, sig_older, order, model_t=None):
+        a_t, s_t = self._as(sig_t)
+        a_s0, s_s0 = self._as(sig_s0)
+        lam_t, lam_s0 = torch.log(a_t) - torch.log(s_t), torch.log(a_s0) - torch.log(s_s0)
+        h = lam_t - lam_s0
+        rks, D1s = [], []
+        for mi, sg in zip(older[:order - 1], sig_older[:order - 1]):
+            a_i, s_i = self._as(sg)
+            rk = (torch.log(a_i) - torch.log(s_i) - lam_s0) / h
+            rks.append(rk)
+            D1s.append((mi - m0) / rk)
+        rks.append(torch.tensor(1.0, dtype=torch.float64))
+        rks = torch.stack([torch.as_tensor(r, dtype=torch.float64) for r in rks])
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.solver_type == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        R, b = torch.stack(R), torch.stack([torch.as_tensor(v, dtype=torch.float64) for v in b])
+        x_t_ = s_t / s_s0 * x - a_t * h_phi_1 * m0
+        if model_t is None:                                  # predictor
+            res = 0
+            if D1s:
+                rhos = torch.tensor([0.5], dtype=torch.float64) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+                res = sum(r * d for r, d in zip(rhos, D1s))
+            return x_t_ - a_t * B_h * res
+        rhos = torch.tensor([0.5], dtype=torch.float64) if order == 1 else torch.linalg.solve(R, b)
+        res = sum(r * d for r, d in zip(rhos[:-1], D1s)) if D1s else 0
+        return x_t_ - a_t * B_h * (res + rhos[-1] * (model_t - m0))
+
+    def step(self, eps, t, sample):
+        k = self.step_index
+        sg = self.sigmas
+        a_t, s_t = self._as(sg[k])
+        x0 = (sample.double() - s_t * eps.double()) / a_t
+        if k > 0 and self.last_sample is not None:
+            older = [self.model_outputs[-2]] if k >= 2 else []
+            sample = self._update(self.last_sample, self.model_outputs[-1], older, sg[k], sg[k - 1], [sg[k - 2]] if k >= 2 else [],
+                                  self.this_order, model_t=x0)
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        order = min(self.order, len(self.timesteps) - k)
+        self.this_order = min(order, self.lower_order_nums + 1)
+        self.last_sample = sample.double()
+        older = [self.model_outputs[-2]] if k >= 1 else []
+        prev = self._update(self.last_sample, x0, older, sg[k + 1], sg[k], [sg[k - 1]] if k >= 1 else [], self.this_order)
+        if self.lower_order_nums < self.order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev.float()
+
+
 def prepare_control(control_u8):
     """VaeImageProcessor(do_normalize=False).preprocess: u8 HWC RGB -> [1,3,H,W] in [0,1]."""
     x = torch.from_numpy(np.ascontiguousarray(control_u8)).float() / 255.0
@@ -118,7 +203,7 @@ def postprocess(img):
 
 @torch.no_grad()
 def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents, steps,
-                           guidance_scale=7.5, conditioning_scale=0.75, return_latents=False, trace=None):
+                           guidance_scale=7.5, conditioning_scale=0.75, return_latents=False, trace=None, sampler="ddim"):
     """weights: dict(unet=, controlnet=, vae=, text=) of diffusers-named state dicts.
     ids_*: int64 [1,77].  control_u8: u8 [H,W,3].  latents: fp32 [1,4,H/8,W/8] noise.
     Returns u8 [1,H,W,3] (and the final latents / decoded float image if asked).  `trace` (a list) receives one
@@ -127,7 +212,7 @@ def sd_controlnet_pipeline(weights, cfgs, ids_pos, ids_neg, control_u8, latents,
     ctx = M.clip_text_forward(weights["text"], cfgs["text"], torch.cat([ids_neg, ids_pos], 0))
     cond = prepare_control(control_u8)
     cond2 = torch.cat([cond, cond], 0)
-    sch = DDIM()
+    sch = DDIM() if sampler == "ddim" else UniPC()
     x = latents.clone().float() * sch.init_noise_sigma
     for t in sch.set_timesteps(steps):
         x2 = torch.cat([x, x], 0)

@@ -155,6 +155,69 @@ __global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hi
   }
 }
 
+// CFG + one UniPC step (UniPCMultistepScheduler, solver_order <= 2, predict_x0; saspa_aug_amd/scheduler.py derives the row):
+//   x0 = (x - r[1] * e) * r[0];  if r[2]: x = r[3] * last + r[4] * m0 + r[5] * m1 + r[6] * x0   (corrector)
+//   m1, m0, last = m0, x0, x;    x = r[7] * x + r[8] * m0 + r[9] * m1                          (predictor)
+// state = [last | m0 | m1], each [nimg][hw][8] in the activation dtype.  row = 12 floats, from the launch arguments or
+// from row *index of a device table (hipGraph replays).
+struct UniPcRow { float v[12]; };
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_unipc_kernel(const T* eps, T* x, T* state, int nimg, long long hw, int C, float g, UniPcRow row,
+                                                        const float* table, const int* index) {
+  const long long total = (long long)nimg * hw;
+  const long long half = total * 8;
+  float r[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) r[j] = table ? table[12ll * (*index) + j] : row.v[j];
+  T* last = state;
+  T* m0p = state + half;
+  T* m1p = state + 2 * half;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    float eu[8], ec[8], xv[8], lv[8], m0[8], m1[8], x0[8], o[8];
+    load8(eps + it * 8, eu);
+    load8(eps + half + it * 8, ec);
+    load8(x + it * 8, xv);
+    load8(m0p + it * 8, m0);
+    load8(m1p + it * 8, m1);
+    if (r[2] != 0.f) load8(last + it * 8, lv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = eu[j] + g * (ec[j] - eu[j]);
+      x0[j] = (xv[j] - r[1] * e) * r[0];
+      float xc = xv[j];
+      if (r[2] != 0.f) xc = r[3] * lv[j] + r[4] * m0[j] + r[5] * m1[j] + r[6] * x0[j];
+      lv[j] = (j < C) ? xc : 0.f;
+      o[j] = (j < C) ? (r[7] * xc + r[8] * x0[j] + r[9] * m0[j]) : 0.f;        // new m0 = x0, new m1 = old m0
+      if (j >= C) x0[j] = 0.f;
+    }
+    store8(last + it * 8, lv);
+    store8(m1p + it * 8, m0);
+    store8(m0p + it * 8, x0);
+    store8(x + it * 8, o);
+    store8(x + half + it * 8, o);
+  }
+}
+
+extern "C" int saspa_cfg_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc,
+                                    float guidance, const float* row, const float* table, const int* index, void* stream) {
+  if (!eps || !x || !state || nimg <= 0 || hw <= 0 || C <= 0 || (!row && !(table && index))) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x) || !aligned16(state)) return SASPA_EALIGN;
+  UniPcRow rr{};
+  if (row && !table)
+    for (int j = 0; j < 12; ++j) rr.v[j] = row[j];
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL(cfg_unipc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, (bf16_t*)state, nimg, hw, C, guidance, rr, table, index);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL(cfg_unipc_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, (float*)state, nimg, hw, C, guidance, rr, table, index);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
 // CFG + DDIM (eta = 0).  One item = one pixel (ldc == 8 channels, C live).
 // CFG == false: plain DDIM step on nimg samples (guidance off: SDXL-Turbo, run_aug/run_aug.py:568).
 // coefs != nullptr: the four coefficients come from row *index of a device table [steps][4] (hipGraph replays: one

@@ -463,6 +463,19 @@ def cfg_plms_step_dev(eps, x, hist, saved, nimg, hw, c, guidance, table, index):
     return x
 
 
+def cfg_unipc_step(eps, x, state, nimg, hw, c, guidance, row=None, table=None, index=None):
+    """CFG + one UniPC step; state [3, nimg, hw, 8] (last | m0 | m1).  `row`: 12 host floats, or (`table` fp32 [steps, 12],
+    `index` int32 [1]) on the device."""
+    _check_dev(eps, x, state, table, index)
+    if table is not None and (table.dtype != torch.float32 or table.dim() != 2 or table.shape[1] != 12 or not table.is_contiguous()
+                              or index is None or index.dtype != torch.int32):
+        raise ValueError("cfg_unipc_step: table fp32 [steps, 12], int32 index")
+    r = None if row is None else (C.c_float * 12)(*[float(v) for v in row])
+    _lib.check(_lib.load().saspa_cfg_unipc_step(_dt(x), _ptr(eps), _ptr(x), _ptr(state), nimg, hw, c, 8, float(guidance), r,
+                                                _ptr(table), _ptr(index), _stream()), "saspa_cfg_unipc_step")
+    return x
+
+
 def index_add(index, delta=1):
     _check_dev(index)
     _lib.check(_lib.load().saspa_index_add(_ptr(index), int(delta), _stream()), "saspa_index_add")

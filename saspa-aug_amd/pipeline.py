@@ -24,7 +24,7 @@ from PIL import Image
 from . import models, ops
 from . import weights as W
 from .config import BLIP_DIFFUSION, BLIP_IMAGE_MEAN, BLIP_IMAGE_STD, SD15, SDXL_TURBO
-from .scheduler import SDXL_TURBO_SCHEDULER_CONFIG, DDIMScheduler, PNDMScheduler
+from .scheduler import SDXL_TURBO_SCHEDULER_CONFIG, DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler
 from .tokenizer import make_bert_tokenizer, make_tokenizer
 
 
@@ -61,7 +61,12 @@ class _StepGraph:
         self.cemb = torch.zeros(cemb_shape, device=dev, dtype=dt)
         self.idx = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.plms = isinstance(pipe.scheduler, PNDMScheduler)
-        if self.plms:       # N + 1 evaluations; per-evaluation parameters, the 4-slot history ring and the saved sample
+        self.unipc = isinstance(pipe.scheduler, UniPCMultistepScheduler)
+        if self.unipc:      # per-step coefficient rows; last sample + two x0-predictions in one static buffer
+            self.evals = steps
+            self.coefs = torch.zeros((steps, UniPCMultistepScheduler.ROW), device=dev, dtype=torch.float32)
+            self.state = torch.zeros((3, x_shape[0] // 2) + tuple(x_shape[1:]), device=dev, dtype=dt)
+        elif self.plms:       # N + 1 evaluations; per-evaluation parameters, the 4-slot history ring and the saved sample
             self.evals = steps + 1
             self.coefs = torch.zeros((self.evals, 10), device=dev, dtype=torch.float32)
             self.hist = torch.zeros((4, x_shape[0] // 2) + tuple(x_shape[1:]), device=dev, dtype=dt)
@@ -101,7 +106,11 @@ class _StepGraph:
                     self.ctx_kv[i][t][1].copy_(vt)
         self.x.copy_(x)
         self.cemb.copy_(cemb)
-        if self.plms:
+        if self.unipc:
+            if first:
+                self.coefs.copy_(torch.tensor(self.plan, dtype=torch.float32))
+            self.state.zero_()
+        elif self.plms:
             if first:
                 rows = [[d["store_slot"], d["w_cur"], *d["w_hist"], d["coef_sample"], d["coef_model"], float(d["save_sample"]),
                          float(d["use_saved"])] for d in self.plan]
@@ -135,7 +144,9 @@ class _StepGraph:
         pipe.unet.decode(mid2, skips2, None, out=self.eps)
         nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
         nc, hw = pipe.cfgs["unet"]["out_channels"], x.shape[1] * x.shape[2]
-        if self.plms:
+        if self.unipc:
+            ops.cfg_unipc_step(self.eps, x, self.state, nimg, hw, nc, self.guidance, table=self.coefs, index=self.idx)
+        elif self.plms:
             ops.cfg_plms_step_dev(self.eps, x, self.hist, self.saved, nimg, hw, nc, self.guidance, self.coefs, self.idx)
         else:
             ops.ddim_step_dev(self.eps, x, nimg, hw, nc, self.guidance, self.coefs, self.idx, cfg=self.cfg)
@@ -157,6 +168,8 @@ class _StepGraph:
             self.idx.zero_()
             if self.plms:
                 self.hist.zero_()
+            if self.unipc:
+                self.state.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step()
@@ -293,6 +306,11 @@ class StableDiffusionControlNetPipeline:
             if isinstance(sch, PNDMScheduler):
                 plan = sch.plan(steps)                 # N+1 evaluations, the second timestep twice
                 ts, plan = [t for t, _ in plan], [d for _, d in plan]
+            elif isinstance(sch, UniPCMultistepScheduler):
+                if t_start:
+                    raise NotImplementedError("img2img with UniPC: the multistep history would have to start mid-schedule")
+                plan = sch.plan(steps)
+                ts, plan = [t for t, _ in plan], [r for _, r in plan]
             else:
                 ts, plan = list(sch.set_timesteps(steps))[t_start:], None
             x2.copy_(self._step_graph(x2, cemb2, ctx, len(ts) if t_start else steps, True, guidance_scale, cscale, ts).run_on(x2, cemb2, ctx, ts, plan=plan))
@@ -319,6 +337,17 @@ class StableDiffusionControlNetPipeline:
                 evaluate(i)
                 ops.cfg_plms_step(eps, x2, hist, saved if d["use_saved"] else None, b, hw, nc, guidance_scale,
                                   d["store_slot"], d["w_cur"], d["w_hist"], d["coef_sample"], d["coef_model"])
+        elif isinstance(sch, UniPCMultistepScheduler):
+            if t_start:
+                raise NotImplementedError("img2img with UniPC: the multistep history would have to start mid-schedule")
+            plan = sch.plan(steps)
+            ts = [t for t, _ in plan]
+            self.unet.prepare_timesteps(ts)
+            self.controlnet.prepare_timesteps(ts)
+            state = torch.zeros((3,) + tuple(x2[:b].shape), device=x2.device, dtype=x2.dtype)
+            for i, (t, row) in enumerate(plan):
+                evaluate(i)
+                ops.cfg_unipc_step(eps, x2, state, b, hw, nc, guidance_scale, row=row)
         else:
             ts = list(sch.set_timesteps(steps))[t_start:]
             self.unet.prepare_timesteps(ts)

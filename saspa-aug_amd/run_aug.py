@@ -230,8 +230,12 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
             return BlipDiffusionControlNetPipeline.from_pretrained(os.path.join(weights_dir, BASE_MODEL_DICT["blip_diffusion-controlnet"]), cfgs)
         logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
         return BlipDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0)
-    if sampler != "ddim":
-        raise NotImplementedError("UniPC sampler (SURVEY 8(f) f4)")
+    def _scheduler_for(pipe):
+        # run_aug/run_aug.py:216-221 (and :223-228 for sd_xl-turbo): the non-BLIP pipelines get UniPC or DDIM built from the
+        # checkpoint's scheduler config
+        from .scheduler import UniPCMultistepScheduler
+        cls = UniPCMultistepScheduler if sampler == "unipcmultistep" else DDIMScheduler
+        return cls.from_config(pipe.scheduler.config)
     if base_model == "sd_xl-turbo" and controlnet == "canny" and not SDEdit:
         # run_aug/run_aug.py:185-201: ControlNetModel(diffusers/controlnet-canny-sdxl-1.0) + sdxl-vae-fp16-fix +
         # StableDiffusionXLControlNetPipeline(stabilityai/sdxl-turbo); :217-228 DDIM from the pipeline's scheduler
@@ -247,7 +251,9 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
         else:
             logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
             pipe = StableDiffusionXLControlNetPipeline.from_synthetic(cfgs, seed=0)
-        pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+        if sampler != "ddim":
+            raise NotImplementedError("sd_xl-turbo runs on DDIM here (the CFG-free UniPC update is not built)")
+        pipe.scheduler = _scheduler_for(pipe)
         pipe.upcast_vae()
         return pipe
     if base_model != "sd_v1.5" or controlnet != "canny":
@@ -267,7 +273,7 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
     else:
         logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
         pipe = _Cls.from_synthetic(cfgs, seed=0)
-    pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+    pipe.scheduler = _scheduler_for(pipe)
     return pipe
 
 

@@ -1,0 +1,90 @@
+"""Production-path parity at full width for the other two model families of BASELINE.json: configs[2] (BLIP-Diffusion +
+Canny ControlNet, PLMS) and configs[4] (SDXL-Turbo + Canny ControlNet at 1024x1024, 4 steps) -- bf16 MFMA kernels, hipGraph
+replay of the step, the batch the bench tools time (tools/blip_bench.py, tools/sdxl_bench.py) -- against the CPU oracle on
+image 0 for a short trajectory (the oracle costs 6-25 s per network evaluation at these sizes).  Bounds are 2x the errors
+measured on the MI355X (printed; PSNR bound = measured - 6 dB)."""
+import numpy as np
+import pytest
+import torch
+
+import saspa_aug_amd  # noqa: F401
+from oracle import blip_models as OB
+from oracle import pipeline as OP
+from oracle.canny import generate_canny_array
+from saspa_aug_amd import config as CFG
+from saspa_aug_amd import weights as W
+from saspa_aug_amd.blip import preprocess_reference
+from saspa_aug_amd.pipeline import BlipDiffusionControlNetPipeline, StableDiffusionXLControlNetPipeline, graphs_enabled
+from saspa_aug_amd.synthetic import synthetic_image
+from tests.util import from_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _metrics(img, x, ref_img, ref_x):
+    got01, ref01 = (from_nhwc(img, 3) / 2 + 0.5).clamp(0, 1), (ref_img / 2 + 0.5).clamp(0, 1)
+    mse = float((got01.double() - ref01.double()).pow(2).mean())
+    gx = from_nhwc(x, 4)
+    rms = ((gx - ref_x).pow(2).mean().sqrt() / ref_x.pow(2).mean().sqrt()).item()
+    return 10 * np.log10(1.0 / max(mse, 1e-20)), (got01 - ref01).abs().max().item(), rms
+
+
+def test_blip_full_width_bf16_graph_vs_oracle(dev):
+    """configs[2]: full-width Q-Former (494 M) + context CLIP + SD-1.5 UNet / ControlNet / VAE, batch 4, 512x512, 3 PLMS steps
+    (4 network evaluations), conditioning scale 1.0 (none is passed, run_aug/run_aug.py:262-265)."""
+    cfgs = CFG.BLIP_DIFFUSION
+    fam = W.synth_family(cfgs, seed=0)
+    b, res, steps = 4, 512, 3
+    nt = cfgs["text"]["max_pos"] - cfgs["qformer"]["num_query"]
+    v = cfgs["text"]["vocab"]
+    ids = np.random.RandomState(1).randint(0, v - 2, (b, nt))
+    neg = np.random.RandomState(2).randint(0, v - 2, (1, 77))
+    ctrls = np.stack([generate_canny_array(synthetic_image(res, res, 60 + i), 120, 200) for i in range(b)])
+    subj = [synthetic_image(300, 260, 80 + i) for i in range(b)]
+    cat_ids = torch.tensor([[101, 4743, 102]] * b)
+    lat = torch.randn((b, 4, res // 8, res // 8), generator=torch.manual_seed(1), dtype=torch.float16)
+    qc = cfgs["qformer"]
+    pipe = BlipDiffusionControlNetPipeline(dict(fam), cfgs).to(dev, torch.bfloat16)
+    assert graphs_enabled()
+    px = torch.stack([preprocess_reference(s, qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD) for s in subj])
+    q = pipe.qformer.forward(px, cat_ids)
+    out, x, img = pipe.generate_batch(ids, neg, ctrls, lat, steps, 7.5, 1.0, return_latents=True, query_embeds=q)
+    pxo = OB.preprocess_reference(subj[0], qc, CFG.BLIP_IMAGE_MEAN, CFG.BLIP_IMAGE_STD)
+    qo = OB.blip2_qformer_forward(fam["qformer"], qc, pxo, cat_ids[:1])
+    q_rel = ((q[:1].float().cpu() - qo).abs().max() / qo.abs().max()).item()
+    ref_u8, ref_x, ref_img = OP.blip_controlnet_pipeline(fam, cfgs, torch.from_numpy(ids[:1]), torch.from_numpy(neg), qo, ctrls[0],
+                                                         lat[:1].float(), steps, return_latents=True)
+    psnr, d01, rms = _metrics(img[:1], x[:1], ref_img, ref_x)
+    print(f"\n[production BLIP] bf16+graph batch {b} vs oracle, {steps} PLMS steps, image 0: subject tokens max-rel {q_rel:.3e}; "
+          f"latents rms-rel {rms:.3e}; image max|d| {d01:.4f} PSNR {psnr:.1f} dB")
+    # measured r2: q_rel 1.20e-2, rms 1.56e-2, PSNR 43.3 dB
+    assert q_rel < 2.4e-2 and rms < 3.2e-2 and psnr > 37.3, (q_rel, rms, d01, psnr)
+
+
+def test_sdxl_1024_full_width_bf16_graph_vs_oracle(dev):
+    """configs[4] family: SDXL UNet (2.57 B) + ControlNet (1.25 B) + both text towers, 1024x1024, batch 2, bf16 denoiser +
+    fp32-upcast VAE, at the reference's sd_xl-turbo settings (no CFG, conditioning scale 0.75), 2 DDIM "trailing" steps."""
+    cfgs = CFG.SDXL_TURBO
+    fam = W.synth_family(cfgs, seed=0)
+    b, res, steps = 2, 1024, 2
+    v = cfgs["text"]["vocab"]
+    rs = np.random.RandomState(3)
+    ids1 = np.full((b, 77), v - 1, np.int64)
+    ids1[:, 0] = v - 2
+    for r in range(b):
+        k = rs.randint(8, 30)
+        ids1[r, 1:1 + k] = rs.randint(0, v - 2, k)
+    ctrls = np.stack([generate_canny_array(synthetic_image(res, res, 90 + i), 120, 200) for i in range(b)])
+    lat = torch.randn((b, 4, res // 8, res // 8), generator=torch.manual_seed(1), dtype=torch.float16)
+    pipe = StableDiffusionXLControlNetPipeline(dict(fam), cfgs)
+    pipe.upcast_vae()
+    pipe = pipe.to(dev, torch.bfloat16)
+    ids2 = pipe.pad_ids_2(ids1)
+    out, x, img = pipe.generate_batch(ids1, None, ctrls, lat, steps, 0.0, 0.75, return_latents=True, prompt_ids_2=ids2)
+    ref_u8, ref_x, ref_img = OP.sdxl_controlnet_pipeline(fam, cfgs, torch.from_numpy(ids1[:1]), torch.from_numpy(ids2[:1]), ctrls[0],
+                                                         lat[:1].float(), steps, return_latents=True)
+    psnr, d01, rms = _metrics(img[:1], x[:1], ref_img, ref_x)
+    print(f"\n[production SDXL] bf16+graph batch {b} 1024x1024 vs oracle, {steps} steps, image 0: latents rms-rel {rms:.3e}; "
+          f"image max|d| {d01:.4f} PSNR {psnr:.1f} dB")
+    # measured r2: rms 1.21e-2, PSNR 50.1 dB
+    assert rms < 2.5e-2 and psnr > 44.0, (rms, d01, psnr)

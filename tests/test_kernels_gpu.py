@@ -42,6 +42,33 @@ def test_linear(dev, dtype, m, k, n):
     assert_close(out.float().cpu()[:, :n], ref, dtype, what=f"linear {m}x{k}x{n}")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("ks", [2, 5, 8])
+def test_splitk_is_deterministic_and_matches(dev, variant, ks):
+    """Split-K (fp32 slabs + reduce/epilogue launch) on both tile families: repeated launches that alternate two problems
+    on the same recycled slabs give one bit pattern each, and both match the reference."""
+    dtype = torch.bfloat16
+    m, k, n = 1024, 11520, 1280
+    x = q(_rand(m, k, seed=61), dtype)
+    w = q(_rand(n, k, seed=62, scale=1 / math.sqrt(k)), dtype)
+    b = _rand(n, seed=63)
+    res = q(_rand(m, n, seed=64), dtype)
+    ref = F.silu(x @ w.t() + b) + res
+    xd, wd, bd, rd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev), res.to(dev, dtype)
+    x2 = -0.5 * xd                      # alternate two problems on the same (recycled) slabs: a stale slab line would show
+    outs, outs2 = [], []
+    for _ in range(8):
+        outs.append(ops.linear(xd, wd, bd, residual=rd, act=ops.ACT_SILU, variant=variant, ksplit=ks))
+        outs2.append(ops.linear(x2, wd, bd, residual=rd, act=ops.ACT_SILU, variant=variant, ksplit=ks))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    for o in outs2[1:]:
+        assert torch.equal(o, outs2[0])
+    assert_close(outs[0].float().cpu(), ref, dtype, what=f"split-K variant {variant} ks {ks}")
+    assert_close(outs2[0].float().cpu(), F.silu(-0.5 * x @ w.t() + b) + res, dtype, what=f"split-K (2nd problem) variant {variant} ks {ks}")
+
+
 @pytest.mark.parametrize("m,k,f", [(4096, 320, 1280), (300, 64, 128), (1024, 128, 640)])
 def test_linear_fused_geglu(dev, m, k, f):
     """GEGLU fused into the projection epilogue (value / gate rows regrouped per output tile)."""

@@ -124,7 +124,8 @@ def test_unet_controlnet_full_width_step(dev, dtype):
     cfgs = CFG.SD15
     fam = dict(unet=W.synth_state_dict("unet", cfgs["unet"], 0), controlnet=W.synth_state_dict("controlnet", cfgs["controlnet"], 1))
     e = _unet_cn_case(cfgs, fam, dev, dtype, 2, 16, 16)
-    assert max(e) < (5e-4 if dtype == torch.float32 else 8e-2), e
+    print(f"full-width UNet+ControlNet step {dtype}: max-rel errors {e}")
+    assert max(e) < (1e-5 if dtype == torch.float32 else 3.5e-2), e      # 2x the measured 3.5e-6 / 1.74e-2 (r2)
 
 
 def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg=1):
@@ -159,7 +160,7 @@ def test_pipeline_bf16_tiny(dev, tiny):
     cfgs, fam = tiny
     d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.bfloat16, 64, 64, 10, nimg=2)
     print(f"bf16 10-step tiny pipeline: max|d|={d01:.4f} (u8 {du8}) PSNR={psnr:.1f} dB")
-    assert psnr > 25.0, (d01, du8, psnr)
+    assert psnr > 34.9, (d01, du8, psnr)                                # measured 40.9 dB (r2); 2x the error = -6 dB
 
 
 def test_pipeline_call_form(dev, tiny):

@@ -155,9 +155,10 @@ typedef struct SaspaGroupNormParams {
   int batch, hw, groups;
   float eps;
   const float* gamma; const float* beta;  /* [C] */
-  float* partial;        /* workspace: batch * nsplit * C * 2 floats */
-  int nsplit;
-  float* scale_shift;    /* out: [batch][2][C] */
+  float* partial;        /* workspace: batch * nsplit * C * 2 floats (holds the per-(image, split, slab, group) sums that
+                            saspa_groupnorm_stats leaves for saspa_groupnorm_apply; same p for both calls) */
+  int nsplit;            /* pixel splits of the statistics pass, 1 .. hw */
+  float* scale_shift;    /* unused since ABI 10 (the apply pass derives scale / shift itself); may be NULL */
   int act;
   void* y; int ldy;      /* apply output [batch*hw][C] */
 } SaspaGroupNormParams;

@@ -891,6 +891,15 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       const long long t = (long long)((p.M + 127) / 128) * (p.N / (n160 ? 160 : 128));
       if (ws_on_g && p.variant == SASPA_GEMM_AUTO && nb == 1 && t >= 256 && p.K <= 384 && saspa_gemm_ws_eligible(p)) return saspa_gemm_ws_launch(p, s);
     }
+    if constexpr (sizeof(T) == 2) {
+      // long K and at least two waves of 256 x 320 tiles: the wide kernel (116 vs 142 us at (4096, 10240, 1280))
+      static const bool wide_g = !(getenv("SASPA_GEMM_WIDE_GEGLU") && atoi(getenv("SASPA_GEMM_WIDE_GEGLU")) == 0);   // A/B knob
+      static const int wide_g_k = getenv("SASPA_GEMM_WIDE_GEGLU_K") ? atoi(getenv("SASPA_GEMM_WIDE_GEGLU_K")) : 1024;
+      const bool want = p.variant == SASPA_GEMM_WIDE || (wide_g && p.variant == SASPA_GEMM_AUTO && p.K >= wide_g_k &&
+                                                         (long long)((p.M + 255) / 256) * (p.N / 320) >= 384);
+      if (want && nb == 1 && saspa_gemm_pp_eligible(p)) return saspa_gemm_pp_launch(p, s, 1, 5);
+      if (p.variant == SASPA_GEMM_WIDE) return SASPA_ERANGE;
+    }
     return n160 ? launch<T, 4, 5>(p, s, 1) : launch<T, 4, 4>(p, s, 1);
   }
   static const int force_tile = getenv("SASPA_GEMM_TILE") ? atoi(getenv("SASPA_GEMM_TILE")) : 0;   // tuning knob

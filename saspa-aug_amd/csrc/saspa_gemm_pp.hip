@@ -486,6 +486,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
           }
         }
         __syncthreads();
+        if (p.act == SASPA_ACT_GEGLU) {
+          // weights are packed per 160 columns (weights.pack_geglu): [80 values | their 80 gates]; a 320-wide tile holds
+          // two such groups -> 160 output features per tile row
+          if constexpr (FN == 5) {
+            constexpr int CPR = 20;
+            for (int q = tid; q < 128 * CPR; q += 512) {
+              const int row = q / CPR, ch = q - row * CPR;
+              const int m = cbm * BM + h * 128 + row;
+              if (m >= p.M) continue;
+              const int sub = ch / 10, c10 = ch - sub * 10;
+              float a[8], g[8];
+              unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + sub * 160 + c10 * 8), a);
+              unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + sub * 160 + 80 + c10 * 8), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = fast_gelu_mul(a[e], g[e]);
+              *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + cbn * 160 + ch * 8) = pack8(a);
+            }
+          }
+          __syncthreads();
+          continue;
+        }
         constexpr int CPR = BN / 8;
         for (int q = tid; q < 128 * CPR; q += 512) {
           const int row = q / CPR, ch = q - row * CPR;
@@ -560,7 +581,9 @@ int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
 
 bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
   const int ctot = p.c0 + p.c1;
-  if (p.dtype != SASPA_BF16 || p.act == SASPA_ACT_GEGLU) return false;
+  if (p.dtype != SASPA_BF16) return false;
+  // fused GEGLU: whole 320-column tiles of the per-160 packing, no residual, no K slices (the caller passes ksplit 1)
+  if (p.act == SASPA_ACT_GEGLU && ((p.N % 320) != 0 || p.residual || p.alpha != 1.0f)) return false;
   if ((ctot % 64) != 0 || (p.c1 > 0 && (p.c0 % 64) != 0)) return false;        // a K-tile lies in one tap of one source
   if ((p.N % 8) != 0 || (p.ldo % 8) != 0 || (p.residual && (p.ldr % 8) != 0)) return false;
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;

@@ -1,19 +1,34 @@
 // GroupNorm (NHWC, optional two-source channel concat, optional SiLU) and LayerNorm.
-// HBM-bound: every access is a 16/32-byte vector per lane (8 channels), statistics in fp32
-// per thread, combined in fp64 by the finalize step.  See include/saspa_hip.h.
+// HBM-bound: every access is a 16/32-byte vector per lane (8 channels).  GroupNorm is two launches: per-(image, pixel
+// split, channel slab, group) fp32 sums, then the apply pass, whose every workgroup first combines the (few KB of) sums
+// of ITS image in fp64 -- no finalize launch in between.  See include/saspa_hip.h.
 #include "common.h"
 
 namespace {
 
-// ---- stage 1: per-(batch, split, channel) sum / sum of squares -------------------------
-// grid = (nsplit, batch, slabs); block = 256 threads laid out as cxw chunk-columns x
-// (256/cxw) pixel rows; a "chunk" is 8 consecutive channels.
+// Thread layout shared by both passes: a block is cxw chunk-columns (a "chunk" = 8 consecutive channels) x rows pixel
+// rows, rows = 256 / cxw (threads beyond rows * cxw idle); blockIdx.z picks the slab of cxw chunks.  cxw divides C/8
+// whenever C/8 has a divisor in [16, 128] that keeps >= 90 % of the threads busy (40 for 320 channels, 80 for 640 /
+// 1280 / 2560, 120 for 960 / 1920, ...), so no slab is ragged on the shapes that matter.
+struct GnGeom { int cxw, slabs; };
+GnGeom gn_geometry(int C8) {
+  if (C8 <= 16) return {C8, 1};
+  for (int d = 128; d >= 16; --d)
+    if (C8 % d == 0 && (256 / d) * d >= 230) return {d, C8 / d};
+  return {32, (C8 + 31) / 32};
+}
+
+// ---- stage 1: sum / sum of squares per (image, split, slab, group) --------------------------------
+// grid = (nsplit, batch, slabs).  partial[((b * nsplit + split) * slabs + slab) * groups + g] = (sum, sumsq) over the
+// block's pixels and the channels of group g that lie in the slab (zero if none).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const SaspaGroupNormParams p, int cxw, int pix_per_split) {
   __shared__ float red[256 * 16];
+  __shared__ float chs[2][128 * 8];
   const int tid = threadIdx.x;
-  const int cx = tid % cxw, py = tid / cxw;
   const int rows = 256 / cxw;
+  const bool active = tid < rows * cxw;
+  const int cx = tid % cxw, py = tid / cxw;
   const int C = p.c0 + p.c1;
   const int C8 = C >> 3;
   const int chunk = blockIdx.z * cxw + cx;
@@ -21,7 +36,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const SaspaGroupNormPar
   float s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-  if (chunk < C8) {
+  if (active && chunk < C8) {
     const int ch = chunk * 8;
     const T* src;
     int ld, cc;
@@ -45,72 +60,90 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const SaspaGroupNormPar
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = ss[j]; }
   __syncthreads();
-  // each (chunk column, value) pair is reduced over the pixel rows by one thread
+  // each (chunk column, value) pair is reduced over the pixel rows by one thread -> per-channel sums of the slab in LDS
   for (int wi = tid; wi < cxw * 16; wi += 256) {
     const int col = wi / 16, val = wi % 16;
     float a = 0.f;
     for (int r = 0; r < rows; ++r) a += red[(r * cxw + col) * 16 + val];
-    const int chunk2 = blockIdx.z * cxw + col;
-    if (chunk2 < C8) {
-      const int ch = chunk2 * 8 + (val & 7);
-      float* dst = p.partial + (((long long)b * p.nsplit + split) * C + ch) * 2 + (val >> 3);
-      *dst = a;
-    }
+    chs[val >> 3][col * 8 + (val & 7)] = a;
   }
-}
-
-// ---- stage 2: one wave per (batch, group): fp64 combine -> scale/shift[b][c] --------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const SaspaGroupNormParams p) {
-  const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.y;
-  if (g >= p.groups) return;
-  const int C = p.c0 + p.c1;
+  __syncthreads();
+  // channels -> groups (the part of each group inside this slab), one thread per group
   const int cpg = C / p.groups;
-  double s = 0.0, ss = 0.0;
-  const int items = cpg * p.nsplit;
-  for (int it = lane; it < items; it += 64) {
-    const int sp = it / cpg, cj = it - sp * cpg;
-    const float* src = p.partial + (((long long)b * p.nsplit + sp) * C + g * cpg + cj) * 2;
-    s += (double)src[0];
-    ss += (double)src[1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    ss += __shfl_xor(ss, o, 64);
-  }
-  const double n = (double)cpg * (double)p.hw;
-  const double mean = s / n;
-  double var = ss / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-  const float meanf = (float)mean;
-  float* sc = p.scale_shift + (long long)b * 2 * C;
-  float* sh = sc + C;
-  for (int cj = lane; cj < cpg; cj += 64) {
-    const int ch = g * cpg + cj;
-    const float ga = p.gamma[ch] * rstd;
-    sc[ch] = ga;
-    sh[ch] = p.beta[ch] - meanf * ga;
+  const int ch0 = blockIdx.z * cxw * 8, ch1 = min(C, ch0 + cxw * 8);
+  float* dst = p.partial + (((long long)b * p.nsplit + split) * gridDim.z + blockIdx.z) * p.groups * 2;
+  for (int g = tid; g < p.groups; g += 256) {
+    const int lo = max(g * cpg, ch0), hi = min((g + 1) * cpg, ch1);
+    float a = 0.f, q = 0.f;
+    for (int c = lo; c < hi; ++c) { a += chs[0][c - ch0]; q += chs[1][c - ch0]; }
+    dst[2 * g] = a;
+    dst[2 * g + 1] = q;
   }
 }
 
-// ---- apply: y = act(x * scale[b][c] + shift[b][c]) -----------------------------------------
+// ---- stage 2: y = act(x * scale[b][c] + shift[b][c]) -----------------------------------------
+// grid = (nblk, batch, slabs), the block's pixels are [blockIdx.x * ppb, +ppb).  Prologue: the 32 (groups) x nsplit x slabs
+// partial sums of image b -> mean / rstd per group (fp64 combine, 8 threads per group), then each thread derives
+// scale / shift of its own 8 channels once; the main loop is a pure stream.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParams p) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParams p, int cxw, int slabs, int ppb) {
+  __shared__ float2 stat[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
   const int C = p.c0 + p.c1;
   const int C8 = C >> 3;
-  const long long total = (long long)p.batch * p.hw * C8;
-  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-    const long long pix = it / C8;
-    const int chunk = (int)(it - pix * C8);
-    const int b = (int)(pix / p.hw);
-    const int ch = chunk * 8;
-    const T* src;
-    int ld, cc;
-    if (ch < p.c0) { src = reinterpret_cast<const T*>(p.x0); ld = p.ldx0; cc = ch; }
-    else { src = reinterpret_cast<const T*>(p.x1); ld = p.ldx1; cc = ch - p.c0; }
+  const int cpg = C / p.groups;
+  {
+    const int sub = tid & 7;
+    const int nparts = p.nsplit * slabs;
+    const float* base = p.partial + (long long)b * nparts * p.groups * 2;
+    for (int g0 = 0; g0 < p.groups; g0 += 32) {
+      const int g = g0 + (tid >> 3);
+      double sm = 0.0, sq = 0.0;
+      if (g < p.groups) {
+        for (int i = sub; i < nparts; i += 8) {
+          const float2 v = *reinterpret_cast<const float2*>(base + ((long long)i * p.groups + g) * 2);
+          sm += (double)v.x;
+          sq += (double)v.y;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        sm += __shfl_xor(sm, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+      }
+      if (g < p.groups && sub == 0) {
+        const double n = (double)cpg * (double)p.hw;
+        const double mean = sm / n;
+        double var = sq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.eps)));
+      }
+    }
+  }
+  __syncthreads();
+  const int rows = 256 / cxw;
+  if (tid >= rows * cxw) return;
+  const int cx = tid % cxw, py = tid / cxw;
+  const int chunk = blockIdx.z * cxw + cx;
+  if (chunk >= C8) return;
+  const int ch = chunk * 8;
+  float scv[8], shv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float2 st = stat[(ch + j) / cpg];
+    scv[j] = p.gamma[ch + j] * st.y;
+    shv[j] = p.beta[ch + j] - st.x * scv[j];
+  }
+  const T* src;
+  int ld, cc;
+  if (ch < p.c0) { src = reinterpret_cast<const T*>(p.x0); ld = p.ldx0; cc = ch; }
+  else { src = reinterpret_cast<const T*>(p.x1); ld = p.ldx1; cc = ch - p.c0; }
+  const int pbeg = blockIdx.x * ppb;
+  const int pend = min(p.hw, pbeg + ppb);
+  const bool silu = p.act == SASPA_ACT_SILU;
+  for (int px = pbeg + py; px < pend; px += rows) {
+    const long long pix = (long long)b * p.hw + px;
     const T* ptr = src + pix * ld + cc;
     float v[8];
     if constexpr (sizeof(T) == 2) {
@@ -119,16 +152,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
       Elem<T>::load_chunk(ptr, v);
       Elem<T>::load_chunk(ptr + 4, v + 4);
     }
-    const float* sc = p.scale_shift + (long long)b * 2 * C + ch;
-    const float* sh = sc + C;
-    const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 4);
-    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float y = v[j] * scv[j] + shv[j];
-      if (p.act == SASPA_ACT_SILU) y = silu_f(y);
+      if (silu) y = silu_f(y);
       v[j] = y;
     }
     T* dst = reinterpret_cast<T*>(p.y) + pix * p.ldy + ch;
@@ -201,15 +228,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, int ldx, T* 
 }
 
 int check_gn(const SaspaGroupNormParams& p) {
-  if (!p.x0 || !p.gamma || !p.beta || !p.partial || !p.scale_shift) return SASPA_EINVAL;
+  if (!p.x0 || !p.gamma || !p.beta || !p.partial) return SASPA_EINVAL;
   if (p.batch <= 0 || p.hw <= 0 || p.groups <= 0 || p.nsplit <= 0 || p.c0 <= 0 || p.c1 < 0) return SASPA_EINVAL;
   if (p.c1 > 0 && !p.x1) return SASPA_EINVAL;
   if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32) return SASPA_EINVAL;
   const int C = p.c0 + p.c1;
   if (p.c0 % 8 || p.c1 % 8 || p.ldx0 % 8 || (p.c1 > 0 && p.ldx1 % 8)) return SASPA_EALIGN;
-  if (C % p.groups) return SASPA_ERANGE;
-  if (!aligned16(p.x0) || (p.x1 && !aligned16(p.x1)) || !aligned16(p.scale_shift)) return SASPA_EALIGN;
-  if (p.nsplit > p.hw) return SASPA_ERANGE;
+  if (C % p.groups || p.groups > 256) return SASPA_ERANGE;
+  if (!aligned16(p.x0) || (p.x1 && !aligned16(p.x1)) || (reinterpret_cast<uintptr_t>(p.partial) & 7u)) return SASPA_EALIGN;
+  if (p.nsplit > p.hw || p.batch > 65535) return SASPA_ERANGE;
+  // the workspace contract stays batch * nsplit * C * 2 floats; the per-group sums need slabs * groups <= C of it
+  if ((long long)gn_geometry(C / 8).slabs * p.groups > C) return SASPA_ERANGE;
   return 0;
 }
 
@@ -220,15 +249,11 @@ extern "C" int saspa_groupnorm_stats(const SaspaGroupNormParams* pp, void* strea
   const SaspaGroupNormParams& p = *pp;
   if (int e = check_gn(p)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int C8 = (p.c0 + p.c1) / 8;
-  const int cxw = C8 >= 32 ? 32 : 16;
-  const int slabs = (C8 + cxw - 1) / cxw;
+  const GnGeom ge = gn_geometry((p.c0 + p.c1) / 8);
   const int pps = (p.hw + p.nsplit - 1) / p.nsplit;
-  dim3 grid(p.nsplit, p.batch, slabs);
-  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), 0, s, p, cxw, pps);
-  else hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, p, cxw, pps);
-  SASPA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.groups + 3) / 4, p.batch), dim3(256), 0, s, p);
+  dim3 grid(p.nsplit, p.batch, ge.slabs);
+  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), 0, s, p, ge.cxw, pps);
+  else hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, p, ge.cxw, pps);
   SASPA_CHECK_LAUNCH();
   return 0;
 }
@@ -239,11 +264,18 @@ extern "C" int saspa_groupnorm_apply(const SaspaGroupNormParams* pp, void* strea
   if (int e = check_gn(p)) return e;
   if (!p.y || p.ldy % 8 || !aligned16(p.y)) return SASPA_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long long total = (long long)p.batch * p.hw * ((p.c0 + p.c1) / 8);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  const GnGeom ge = gn_geometry((p.c0 + p.c1) / 8);
+  const int rows = 256 / ge.cxw;
+  // about 1024 workgroups in all, each at least two passes of its pixel rows long (amortises the statistics prologue)
+  int nblk = 1024 / (p.batch * ge.slabs);
+  const int most = (p.hw + 2 * rows - 1) / (2 * rows);
+  if (nblk > most) nblk = most;
+  if (nblk < 1) nblk = 1;
+  const int ppb = (p.hw + nblk - 1) / nblk;
+  nblk = (p.hw + ppb - 1) / ppb;
+  dim3 grid(nblk, p.batch, ge.slabs);
+  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p, ge.cxw, ge.slabs, ppb);
+  else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, p, ge.cxw, ge.slabs, ppb);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

@@ -5,6 +5,7 @@ enqueues hand-written gfx950 kernels through ctypes and does no arithmetic of it
 Activations are channels-last ``[B, H, W, C]`` (or ``[M, C]`` token matrices) whose last
 dim is contiguous; the pixel pitch (``stride(-2)``) may exceed C (views into wider
 buffers, e.g. the q/k slices of a fused projection)."""
+import os
 import ctypes as C
 
 import torch
@@ -263,9 +264,10 @@ def softmax_rows(x, n, scale, causal=False, rows_per_mat=1):
 
 
 def _gn_nsplit(batch, hw, c8):
-    slabs = (c8 + 31) // 32 if c8 >= 32 else 1
-    want = max(1, 1024 // max(1, batch * slabs))
-    return max(1, min(want, 256, hw // 16 if hw >= 16 else 1))
+    """Pixel splits of the statistics pass: about 512 workgroups per channel slab (the apply pass re-reads
+    nsplit * slabs * groups sums per workgroup, so no more than needed to fill the chip)."""
+    want = max(1, 512 // max(1, batch))
+    return max(1, min(want, 64, hw // 16 if hw >= 16 else 1))
 
 
 def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
@@ -285,7 +287,6 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
         out = torch.empty((b, h, w, ctot), device=x.device, dtype=x.dtype)
     nsplit = _gn_nsplit(b, h * w, ctot // 8)
     partial = torch.empty((b * nsplit * ctot * 2,), device=x.device, dtype=torch.float32)
-    ss = torch.empty((b, 2, ctot), device=x.device, dtype=torch.float32)
     p = _lib.GroupNormParams()
     p.dtype = _dt(x)
     p.x0, p.x1, p.c0, p.c1 = _ptr(x), _ptr(x2), c0, c1
@@ -293,7 +294,7 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
     p.ldx1 = 0 if x2 is None else _pitch4(x2)
     p.batch, p.hw, p.groups, p.eps = b, h * w, groups, float(eps)
     p.gamma, p.beta = _ptr(gamma), _ptr(beta)
-    p.partial, p.nsplit, p.scale_shift = _ptr(partial), nsplit, _ptr(ss)
+    p.partial, p.nsplit, p.scale_shift = _ptr(partial), nsplit, None
     p.act, p.y, p.ldy = int(act), _ptr(out), _pitch4(out)
     s = _stream()
     _lib.check(lib.saspa_groupnorm_stats(C.byref(p), s), "saspa_groupnorm_stats")

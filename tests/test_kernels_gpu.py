@@ -69,8 +69,10 @@ def test_splitk_is_deterministic_and_matches(dev, variant, ks):
     assert_close(outs2[0].float().cpu(), F.silu(-0.5 * x @ w.t() + b) + res, dtype, what=f"split-K (2nd problem) variant {variant} ks {ks}")
 
 
-@pytest.mark.parametrize("m,k,f", [(4096, 320, 1280), (300, 64, 128), (1024, 128, 640)])
-def test_linear_fused_geglu(dev, m, k, f):
+@pytest.mark.parametrize("m,k,f,variant", [(4096, 320, 1280, 0), (300, 64, 128, 0), (1024, 128, 640, 0),
+                                           (4096, 320, 1280, 2), (1000, 128, 640, 2),     # 8-wave 256x320 tiles (two packed groups per tile)
+                                           (4096, 1280, 5120, 0)])                          # AUTO picks the wide kernel
+def test_linear_fused_geglu(dev, m, k, f, variant):
     """GEGLU fused into the projection epilogue (value / gate rows regrouped per output tile)."""
     dtype = torch.bfloat16
     x = q(_rand(m, k, seed=50), dtype)
@@ -79,7 +81,7 @@ def test_linear_fused_geglu(dev, m, k, f):
     h = x @ w.t() + b
     ref = h[:, :f] * F.gelu(h[:, f:])
     wp, bp = W.pack_geglu(w, b)
-    out = ops.linear(x.to(dev, dtype), wp.to(dev, dtype), bp.to(dev), act=ops.ACT_GEGLU)
+    out = ops.linear(x.to(dev, dtype), wp.to(dev, dtype), bp.to(dev), act=ops.ACT_GEGLU, variant=variant)
     assert out.shape == (m, f)
     assert_close(out.float().cpu(), ref, dtype, what=f"fused geglu {m}x{k}x{f}")
 
@@ -274,7 +276,10 @@ def test_softmax_rows(dev, dtype, causal):
 # ------------------------------------------------------------------ norms / elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,h,w_,c,groups,act", [(2, 16, 16, 320, 32, 1), (2, 8, 8, 64, 8, 0), (1, 64, 64, 128, 32, 1),
-                                                   (3, 5, 7, 40, 5, 0), (2, 8, 8, 2560, 32, 1)])
+                                                   (3, 5, 7, 40, 5, 0), (2, 8, 8, 2560, 32, 1),
+                                                   (2, 8, 11, 960, 32, 1),      # 120 chunk columns x 2 rows, ragged pixel splits
+                                                   (2, 16, 16, 1920, 32, 1), (16, 32, 32, 640, 32, 1),
+                                                   (1, 6, 6, 1048, 8, 0)])      # 131 chunks (prime): ragged last slab
 def test_groupnorm(dev, dtype, b, h, w_, c, groups, act):
     x = q(_rand(b, c, h, w_, seed=28) * 2 + 0.5, dtype)
     g, be = 1 + 0.1 * _rand(c, seed=29), 0.1 * _rand(c, seed=30)

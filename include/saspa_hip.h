@@ -305,6 +305,21 @@ int saspa_resize_area_u8(const uint8_t* src, uint8_t* dst, int n, int h, int w, 
                          int isx, int isy, void* stream);
 
 /* library self-description */
+/* ---- HED annotator head (run_aug/run_aug.py:311-312, :438-439 -> controlnet_aux HEDdetector.__call__) -------
+ * The network's conv stack runs as saspa_gemm / saspa_pool2d launches; this is what follows it: side output k
+ * ([n][mh][mw] fp32 samples at element pitch ld -- channel 0 of a channel-padded NHWC tensor) is resized to H x W like
+ * cv2.resize(INTER_LINEAR) on float32 (xofs [W] first source column, xw [W][2] weights; yofs [H][2] the two clamped source
+ * rows, yw [H][2] weights: host tables), the nmaps results are averaged in float32 in order, then
+ * u8 = trunc(clip(255 / (1 + exp(-mean)), 0, 255)) in fp64, written to all three channels of dst [n][H][W][3]. */
+typedef struct SaspaHedFuseParams {
+  int nmaps, n, H, W;
+  const float* map[5]; int mh[5], mw[5], ld[5];
+  const int* xofs[5]; const float* xw[5];
+  const int* yofs[5]; const float* yw[5];
+  uint8_t* dst;
+} SaspaHedFuseParams;
+int saspa_hed_fuse(const SaspaHedFuseParams* p, void* stream);
+
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);
 

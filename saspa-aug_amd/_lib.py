@@ -46,6 +46,15 @@ class GroupNormParams(C.Structure):
     ]
 
 
+class HedFuseParams(C.Structure):
+    _fields_ = [
+        ("nmaps", C.c_int), ("n", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("map", C.c_void_p * 5), ("mh", C.c_int * 5), ("mw", C.c_int * 5), ("ld", C.c_int * 5),
+        ("xofs", C.c_void_p * 5), ("xw", C.c_void_p * 5), ("yofs", C.c_void_p * 5), ("yw", C.c_void_p * 5),
+        ("dst", C.c_void_p),
+    ]
+
+
 # every symbol include/saspa_hip.h declares: (name, restype, argtypes)
 _I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 SYMBOLS = {
@@ -77,6 +86,7 @@ SYMBOLS = {
     "saspa_pool2d": (_I, [_I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "saspa_signsqrt_l2norm": (_I, [_P, _LL, _P, _LL, _I, _LL, _F, _F, _P]),
     "saspa_resize_taps_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
+    "saspa_hed_fuse": (_I, [C.POINTER(HedFuseParams), _P]),
     "saspa_resize_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "saspa_vae_sample_noise": (_I, [_I, _P, _P, _P, _P, _LL, _F, _F, _F, _P]),
     "saspa_cfg_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P]),

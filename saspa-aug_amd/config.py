@@ -68,6 +68,12 @@ WSDAN_CAL_R101 = dict(image_size=224, layers=(3, 4, 23, 3), width=64, attentions
 WSDAN_CAL_R50 = dict(image_size=224, layers=(3, 4, 6, 3), width=64, attentions=32)
 
 
+# controlnet_aux HEDdetector network (ControlNetHED_Apache2: VGG-16 conv stack, one 1x1 side output per block); the
+# reference builds it for CONTROLNET = "hed" (run_aug/run_aug.py:311-312)
+HED = dict(blocks=((64, 2), (128, 2), (256, 3), (512, 3), (512, 3)))
+HED_TINY = dict(blocks=((8, 2), (16, 2), (16, 3), (24, 3), (24, 3)))
+
+
 def tiny_filters(num_classes=12):
     """Reduced-width filter models with the same topology (tests)."""
     rn = dict(image_size=64, layers=(1, 1, 1, 1), width=16, heads=4, embed_dim=32, vocab=512, text_width=32, text_heads=2,

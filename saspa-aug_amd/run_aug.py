@@ -256,10 +256,11 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
         pipe.scheduler = _scheduler_for(pipe)
         pipe.upcast_vae()
         return pipe
-    if base_model != "sd_v1.5" or controlnet != "canny":
+    if base_model != "sd_v1.5" or controlnet not in CONTROLNET_DICT_SD:
         raise NotImplementedError(
-            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 (text-to-image and SDEdit img2img), blip_diffusion and "
-            "sd_xl-turbo with the canny ControlNet are built; HED / ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are baseline branches")
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 (text-to-image and SDEdit img2img; canny or HED ControlNet), "
+            "blip_diffusion and sd_xl-turbo with the canny ControlNet are built; ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are "
+            "baseline branches")
     cfgs = cfgs or SD15
     if SDEdit:                                  # run_aug/run_aug.py:203-206: StableDiffusionControlNetImg2ImgPipeline
         from .pipeline import StableDiffusionControlNetImg2ImgPipeline as _Cls
@@ -451,6 +452,18 @@ def make_batches(mine, batch_size):
 # ------------------------------------------------------------------------------------------
 # generation of one batch of work items on the GPU
 # ------------------------------------------------------------------------------------------
+def make_hed_detector(s: Settings, device):
+    """run_aug/run_aug.py:311-312: `HEDdetector.from_pretrained('lllyasviel/ControlNet')` -- from WEIGHTS_DIR when given,
+    architecture-exact synthetic weights otherwise (no checkpoint offline)."""
+    from . import weights as W
+    from .config import HED
+    from .hed import HEDdetector
+    if s.WEIGHTS_DIR:
+        return HEDdetector.from_pretrained(os.path.join(s.WEIGHTS_DIR, "lllyasviel/ControlNet"), device=device)
+    logging.info("no WEIGHTS_DIR given: HED annotator with architecture-exact SYNTHETIC weights")
+    return HEDdetector(W.synth_state_dict("hed", HED, 7), HED, device)
+
+
 def hip_batch_generator(pipe, s: Settings):
     """Returns fn(batch_items, noises[list of [1,4,h,w]], source_u8 [B,H,W,3]) -> (images u8
     [B,H,W,3] numpy, control u8 [B,H,W,3] numpy), running Canny + sampling on the device."""
@@ -459,6 +472,7 @@ def hip_batch_generator(pipe, s: Settings):
     neg_ids = tok(NEGATIVE_PROMPT)
 
     blip = "blip_diffusion" in s.BASE_MODEL
+    hed = make_hed_detector(s, pipe.device) if s.CONTROLNET == "hed" else None
 
     side = torch.cuda.Stream(device=pipe.device)
 
@@ -476,7 +490,10 @@ def hip_batch_generator(pipe, s: Settings):
         """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU.  `sources` /
         `subjects`: decoded images as loaded (lists; a stacked array when they already have the planned size)."""
         src = torch.stack([to_device(raw, it.height, it.width) for raw, it in zip(sources, batch)])
-        ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
+        if hed is not None:                                                    # run_aug/run_aug.py:438-439
+            ctrl = hed.detect_batch(src)
+        else:
+            ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
         lat = torch.cat(noises)
         subs = None
         if blip:

@@ -350,7 +350,20 @@ def wsdan_cal_spec(cfg):
     return spec
 
 
-SPECS.update(clip_rn50=clip_rn50_spec, cal=wsdan_cal_spec, vae_enc=vae_encoder_spec)
+def hed_spec(cfg):
+    """ControlNetHED.pth (controlnet_aux `ControlNetHED_Apache2`): `norm` [1,3,1,1], `block{i}.convs.{j}.{weight,bias}`,
+    `block{i}.projection.{weight,bias}`."""
+    spec = [("norm", (1, 3, 1, 1), "hed_norm")]
+    prev = 3
+    for i, (c, n) in enumerate(cfg["blocks"]):
+        for j in range(n):
+            spec += [(f"block{i + 1}.convs.{j}.weight", (c, prev if j == 0 else c, 3, 3), "w"), (f"block{i + 1}.convs.{j}.bias", (c,), "bias")]
+        spec += [(f"block{i + 1}.projection.weight", (1, c, 1, 1), "w"), (f"block{i + 1}.projection.bias", (1,), "bias")]
+        prev = c
+    return spec
+
+
+SPECS.update(clip_rn50=clip_rn50_spec, cal=wsdan_cal_spec, vae_enc=vae_encoder_spec, hed=hed_spec)
 
 
 def fold_bn(conv_w, sd, bn_pfx, eps=1e-5):
@@ -406,6 +419,8 @@ def synth_state_dict(kind, cfg, seed=0):
             t = torch.randn(shape, generator=g) * 0.05
         elif k == "logit_scale":
             t = torch.tensor(math.log(100.0))
+        elif k == "hed_norm":       # per-channel pixel mean on the 0..255 scale
+            t = 110.0 + 20.0 * torch.rand(shape, generator=g)
         elif k == "thresh":
             # cosine thresholds of the safety checker (the real ones lie around 0.18-0.3): 6 sigma of the cosine of two
             # random proj_dim-vectors (0.217 at 768) so that random weights never flag an image by accident

@@ -66,3 +66,25 @@ def test_run_aug_end_to_end_sdxl_turbo(dev, tmp_path):
     assert (res["status"] == 1).all() and len(res["items"]) == 10
     body = json.load(open(res["json_path"]))
     assert len(body) == 5 and all(len(v) == 2 for v in body.values())
+
+
+def test_run_aug_end_to_end_hed_control(dev, tmp_path):
+    """CONTROLNET = "hed" (run_aug/run_aug.py:311-312, :438-439): the control images come from the HED annotator (batched, on
+    the device), the tree moves to controlnet/sd_v1.5/hed/, everything else is unchanged."""
+    import numpy as np
+    from PIL import Image
+    cfgs = CFG.tiny()
+    pipe = R.init_pipeline("sd_v1.5", "hed", 0, cfgs=cfgs, state_dicts=W.synth_family(cfgs, seed=3)).to("cuda:0", torch.float16)
+    assert isinstance(pipe, StableDiffusionControlNetPipeline)
+    s = _settings(tmp_path, "sd_v1.5", CONTROLNET="hed")
+    s.RESOLUTION, s.NUM_PER_IMAGE, s.NUM_INFERENCE_STEPS = 512, 1, 2
+    s.DATASET_KWARGS = dict(root_path=str(tmp_path / "ds" / "data"), n_images=3, sizes=((512, 512), (512, 576)))
+    res = R.main(s, pipe=pipe)
+    out = Path(res["output_folder"])
+    assert "aug_data/controlnet/sd_v1.5/hed/" in str(out)
+    assert (res["status"] == 1).all() and len(res["items"]) == 3
+    ctrl = sorted(out.glob("*_control.png"))
+    assert len(ctrl) == 3
+    c = np.asarray(Image.open(ctrl[0]))
+    # a grey-level soft edge map with three equal channels, not Canny's {0, 255}
+    assert c.ndim == 3 and np.array_equal(c[..., 0], c[..., 1]) and len(np.unique(c)) > 8

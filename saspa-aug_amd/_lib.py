@@ -107,7 +107,11 @@ def load():
             f"{LIB_PATH} not found: the gfx950 kernels are not built. Run "
             "`make -C saspa-aug_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    # SASPA_HIP_LIB_LENIENT=1 (only with SASPA_HIP_LIB): same-box A/B against an OLDER build that lacks newer symbols
+    lenient = bool(os.environ.get("SASPA_HIP_LIB")) and os.environ.get("SASPA_HIP_LIB_LENIENT") == "1"
     for name, (res, args) in SYMBOLS.items():
+        if lenient and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

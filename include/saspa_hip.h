@@ -32,6 +32,11 @@ extern "C" {
 
 #define SASPA_BF16 0
 #define SASPA_F32 1
+/* saspa_gemm only: fp32 storage (every pointer as for SASPA_F32), products formed as three bf16 MFMAs (x = hi + lo with
+ * hi = bf16(x), lo = bf16(x - hi); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation): ~2^-17 relative per
+ * product instead of 2^-24, at several times the rate of the fp32 MFMA.  For the fp32-upcast SDXL VAE
+ * (run_aug/run_aug.py:224 `pipe.upcast_vae()`), whose range -- not its last 7 bits -- is why the reference leaves fp16. */
+#define SASPA_F32X3 2
 
 #define SASPA_EINVAL (-1) /* null pointer / non-positive size */
 #define SASPA_EALIGN (-2) /* channel count, pitch or pointer not 16-byte compatible */

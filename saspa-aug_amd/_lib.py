@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SASPA_HIP_LIB: load another build of the same ABI (the `make ABLATION=1` diagnostics library of tools/pp_clock.py ...)
 LIB_PATH = os.environ.get("SASPA_HIP_LIB") or os.path.join(_HERE, "libsaspa_hip.so")
 
-SASPA_BF16, SASPA_F32 = 0, 1
+SASPA_BF16, SASPA_F32, SASPA_F32X3 = 0, 1, 2
 ERRORS = {-1: "SASPA_EINVAL (null pointer / bad size)", -2: "SASPA_EALIGN (16-byte alignment / channel multiple)",
           -3: "SASPA_ERANGE (unsupported shape)"}
 

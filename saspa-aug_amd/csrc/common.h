@@ -91,6 +91,20 @@ template <> struct Elem<float> {
   __device__ static __forceinline__ void store1(float* p, float f) { *p = f; }
 };
 
+// fp32 storage whose GEMMs run as three bf16 MFMAs per product (x = hi + lo, hi = bf16(x), lo = bf16(x - hi);
+// a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, the a_lo b_lo term of relative size 2^-18 is dropped): SASPA_F32X3.
+// Same size / layout as float, so every loader, epilogue and index computation is shared with the exact-fp32 path.
+struct f32x3_t { float v; };
+template <> struct Elem<f32x3_t> {
+  static constexpr int EPC = 4;
+  __device__ static __forceinline__ void load_chunk(const f32x3_t* p, float* f) { Elem<float>::load_chunk(reinterpret_cast<const float*>(p), f); }
+  __device__ static __forceinline__ void store_chunk(f32x3_t* p, const float* f) { Elem<float>::store_chunk(reinterpret_cast<float*>(p), f); }
+  __device__ static __forceinline__ void load4(const f32x3_t* p, float* f) { Elem<float>::load4(reinterpret_cast<const float*>(p), f); }
+  __device__ static __forceinline__ void store4(f32x3_t* p, const float* f) { Elem<float>::store4(reinterpret_cast<float*>(p), f); }
+  __device__ static __forceinline__ float load1(const f32x3_t* p) { return p->v; }
+  __device__ static __forceinline__ void store1(f32x3_t* p, float f) { p->v = f; }
+};
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 // activation applied BEFORE the residual add (SiLU, ReLU) / AFTER it (ReLU of ResNet bottlenecks); see saspa_hip.h
 __device__ __forceinline__ float act_pre(int act, float x) {

@@ -59,6 +59,32 @@ template <> struct Mma<float> {
   }
 };
 
+template <> struct Mma<f32x3_t> {
+  // per-chunk form (generic loader kernel, fp32 parity of odd shapes): the exact fp32 chain
+  __device__ static __forceinline__ void run(const u32x4& wf, const u32x4& xf, f32x4& acc) { Mma<float>::run(wf, xf, acc); }
+  // 8 fp32 values of one lane (its two 16-byte chunks of the K-tile) -> 8 bf16 "hi" + 8 bf16 "lo" (round to nearest)
+  __device__ static __forceinline__ void split(const u32x4& f0, const u32x4& f1, u32x4& hi, u32x4& lo) {
+    const f32x4 a = __builtin_bit_cast(f32x4, f0), b = __builtin_bit_cast(f32x4, f1);
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t hp = pack2(x[2 * q], x[2 * q + 1]);
+      h[q] = hp;
+      l[q] = pack2(x[2 * q] - __builtin_bit_cast(float, hp << 16), x[2 * q + 1] - __builtin_bit_cast(float, hp & 0xffff0000u));
+    }
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+  }
+  __device__ static __forceinline__ void run3(const u32x4& wh, const u32x4& wl, const u32x4& xh, const u32x4& xl, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xh), acc, 0, 0, 0);
+  }
+};
+template <typename T> struct is_x3 { static constexpr bool value = false; };
+template <> struct is_x3<f32x3_t> { static constexpr bool value = true; };
+
 // ---- shared epilogue of both kernel variants ------------------------------------------
 // split-K: raw fp32 slab.  bf16: the tile goes through LDS so that global stores (and the
 // residual read) are whole 16-byte chunks of contiguous output rows; GEGLU pairs the value /
@@ -705,6 +731,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
     if (abl & 2) return;
     const u32x4* la = lds + stage * STAGE;
     const u32x4* lb = la + BM * 8;
+    if constexpr (is_x3<T>::value) {
+      // SASPA_F32X3: the lane's two chunks (fg, 4 + fg) are its 8 k values of ONE 16x16x32 bf16 MFMA step -- the same
+      // k assignment for both operands, so any fixed assignment is a valid permutation of the sum
+      u32x4 xh[WM], xl[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * (16 * WM) + i * 16 + frow;
+        Mma<T>::split(la[row * 8 + (fg ^ (row & 7))], la[row * 8 + ((4 + fg) ^ (row & 7))], xh[i], xl[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int row = wn * (16 * WN) + j * 16 + frow;
+        u32x4 wh, wl;
+        Mma<T>::split(lb[row * 8 + (fg ^ (row & 7))], lb[row * 8 + ((4 + fg) ^ (row & 7))], wh, wl);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) Mma<T>::run3(wh, wl, xh[i], xl[i], acc[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int chunk = kk * 4 + fg;
@@ -1003,7 +1048,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (p.nb2 <= 0) p.nb2 = 1;
   if (!p.a0 || !p.w || !p.out) return SASPA_EINVAL;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return SASPA_EINVAL;
-  if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32) return SASPA_EINVAL;
+  if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32 && p.dtype != SASPA_F32X3) return SASPA_EINVAL;
   if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return SASPA_EINVAL;
   if (p.c1 > 0 && !p.a1) return SASPA_EINVAL;
   if (p.c1 < 0 || p.c0 <= 0) return SASPA_EINVAL;
@@ -1056,5 +1101,6 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (p.ksplit > 1 && p.workspace && !aligned16(p.workspace)) return SASPA_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.dtype == SASPA_BF16) return dispatch<bf16_t>(p, s);
+  if (p.dtype == SASPA_F32X3) return dispatch<f32x3_t>(p, s);
   return dispatch<float>(p, s);
 }

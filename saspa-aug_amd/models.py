@@ -447,8 +447,10 @@ class ControlNet(_Net):
 class VAEDecoder:
     """AutoencoderKL.decode."""
 
-    def __init__(self, sd, cfg, dev, dtype):
+    def __init__(self, sd, cfg, dev, dtype, f32_gemm="exact"):
         self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        # fp32 VAE only: "exact" = fp32 MFMA (parity path), "x3" = three bf16 MFMAs per product (ops.f32_gemm_mode)
+        self.f32_gemm = f32_gemm if dtype == torch.float32 else "exact"
         pk = self.pk = _Packed(sd, dev, dtype)
         self.p = pk.p
         pk.conv("post_quant_conv")
@@ -508,9 +510,10 @@ class VAEDecoder:
         esz = 2 if self.dtype == torch.bfloat16 else 4
         per_img = 64 * h * w * self.cfg["block_out"][min(1, len(self.cfg["block_out"]) - 1)] * esz
         chunk = max(1, ((1 << 31) - 1) // per_img)
-        if b <= chunk:
-            return self._decode(z)
-        return torch.cat([self._decode(z[i:i + chunk].contiguous()) for i in range(0, b, chunk)], 0)
+        with ops.f32_gemm_mode(self.f32_gemm):
+            if b <= chunk:
+                return self._decode(z)
+            return torch.cat([self._decode(z[i:i + chunk].contiguous()) for i in range(0, b, chunk)], 0)
 
     def _decode(self, z):
         p, cfg = self.p, self.cfg

@@ -46,6 +46,31 @@ def _dt(t):
     raise TypeError(f"unsupported activation dtype {t.dtype}")
 
 
+_F32_GEMM_MODE = ["exact"]
+
+
+class f32_gemm_mode:
+    """Context: how fp32 GEMMs / convs issued inside run -- "exact" (fp32 MFMA, the parity path) or "x3" (SASPA_F32X3: three
+    bf16 MFMAs per product, ~2^-17 relative; the upcast SDXL VAE).  Storage and every other kernel stay fp32."""
+
+    def __init__(self, mode):
+        if mode not in ("exact", "x3"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _F32_GEMM_MODE[0]
+        _F32_GEMM_MODE[0] = self.mode
+
+    def __exit__(self, *a):
+        _F32_GEMM_MODE[0] = self.prev
+
+
+def _gemm_dt(t):
+    d = _dt(t)
+    return _lib.SASPA_F32X3 if (d == _lib.SASPA_F32 and _F32_GEMM_MODE[0] == "x3") else d
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -140,7 +165,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
         nc = round8(n)
         out = (torch.zeros if nc != n else torch.empty)((b, ho, wo, nc), device=x.device, dtype=x.dtype)
     p = _lib.GemmParams()
-    p.dtype = _dt(x)
+    p.dtype = _gemm_dt(x)
     p.a0, p.a1 = _ptr(x), _ptr(x2)
     p.c0, p.c1 = c0, c1
     p.lda0 = _pitch4(x)
@@ -179,7 +204,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     o2 = out.view(-1, out.shape[-1]) if out.dim() != 2 else out
     r2 = None if residual is None else (residual.reshape(-1, residual.shape[-1]) if residual.dim() != 2 else residual)
     p = _lib.GemmParams()
-    p.dtype = _dt(x)
+    p.dtype = _gemm_dt(x)
     p.a0, p.a1, p.c0, p.c1 = _ptr(x2), None, k, 0
     p.lda0, p.lda1 = (x2.stride(0) if m > 1 else max(k, x2.stride(0))), 0
     p.batch, p.hin, p.win, p.hout, p.wout = 1, m, 1, m, 1
@@ -211,7 +236,7 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     _check_dev(a, w, out, residual)
     lib = _lib.load()
     p = _lib.GemmParams()
-    p.dtype = _dt(a)
+    p.dtype = _gemm_dt(a)
     p.a0, p.a1, p.c0, p.c1, p.lda0, p.lda1 = _ptr(a), None, k, 0, lda, 0
     p.batch, p.hin, p.win, p.hout, p.wout = 1, m, 1, m, 1
     p.kh = p.kw = p.stride = 1

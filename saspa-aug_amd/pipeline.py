@@ -257,7 +257,7 @@ class StableDiffusionControlNetPipeline:
         if "safety" in sd and "safety" in cf:
             self.safety_checker = models.SafetyChecker(sd["safety"], cf["safety"], device, cdt)
 
-    def upcast_vae(self):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
+    def upcast_vae(self, gemm=None):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
         return self
 
     def run_safety_checker(self, images_u8):
@@ -646,6 +646,7 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         self.tokenizer_2 = tokenizer_2 or make_tokenizer(vocab=cfgs["text2"]["vocab"])
         self.text_encoder_2 = None
         self._vae_fp32 = False
+        self._vae_gemm = None
         self._vae_sd = None
 
     @classmethod
@@ -675,18 +676,24 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         self._vae_sd = None if self._state_dicts is None else self._state_dicts["vae"]
         super().to(device, dtype)
         if self._vae_fp32:
-            self.upcast_vae()
+            self.upcast_vae(self._vae_gemm)
         return self
 
     def _build_extra(self, sd, cf, device, cdt):
         self.text_encoder_2 = models.CLIPText(sd["text2"], cf["text2"], device, cdt)
 
-    def upcast_vae(self):
+    def upcast_vae(self, gemm=None):
         """run_aug/run_aug.py:224: the VAE decodes in float32.  Before `.to()` it is recorded; after, the decoder is
-        re-packed for the exact-fp32 kernels from the retained VAE state dict."""
+        re-packed for fp32 storage from the retained VAE state dict.  The reference upcasts because fp16 overflows in this
+        VAE, not for the last mantissa bits: the decoder's GEMMs default to `SASPA_F32X3` (three bf16 MFMAs per product,
+        ~1e-5 relative, well inside the 1e-3 per-pixel bar, several times the fp32 MFMA rate); `gemm="exact"` or
+        SASPA_VAE_EXACT_FP32=1 selects the exact fp32 MFMA path.  GroupNorm / softmax / residuals are fp32 either way."""
         self._vae_fp32 = True
-        if self.vae is not None and self.vae.dtype != torch.float32:
-            self.vae = models.VAEDecoder(self._vae_sd, self.cfgs["vae"], self.device, torch.float32)
+        if gemm is None:
+            gemm = "exact" if os.environ.get("SASPA_VAE_EXACT_FP32", "0") == "1" else "x3"
+        self._vae_gemm = gemm
+        if self.vae is not None and (self.vae.dtype != torch.float32 or self.vae.f32_gemm != gemm):
+            self.vae = models.VAEDecoder(self._vae_sd, self.cfgs["vae"], self.device, torch.float32, f32_gemm=gemm)
         return self
 
     # ---- pieces ------------------------------------------------------------------------

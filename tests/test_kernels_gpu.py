@@ -392,3 +392,39 @@ def test_canny_noise_and_flat(dev):
         got = ops.canny(torch.from_numpy(batch).to(dev), 120, 200).cpu().numpy()
         for i in range(batch.shape[0]):
             assert np.array_equal(got[i], OC.generate_canny_array(batch[i], 120, 200))
+
+
+# ------------------------------------------------------------------ SASPA_F32X3: fp32 storage, three bf16 MFMAs per product
+@pytest.mark.parametrize("case", [("linear", 1000, 512, 320), ("linear", 4096, 1280, 640), ("conv", 2, 32, 32, 128, 256),
+                                  ("conv_up", 1, 16, 16, 256, 128), ("conv_small", 2, 8, 8, 4, 64)])
+def test_f32x3_gemm(dev, case):
+    """hi/lo split products: ~2^-17 relative per product against fp64, orders of magnitude inside bf16's 2^-9 and the
+    1e-3 per-pixel bar; odd shapes (K not a multiple of 32) fall back to the exact fp32 chain."""
+    kind = case[0]
+    if kind == "linear":
+        _, m, k, n = case
+        x = _rand(m, k, seed=80) * 3 + 0.3
+        w = _rand(n, k, seed=81, scale=1 / math.sqrt(k))
+        b = _rand(n, seed=82)
+        ref = (x.double() @ w.double().t() + b.double())
+        with ops.f32_gemm_mode("x3"):
+            got = ops.linear(x.to(dev), w.to(dev), b.to(dev)).cpu()[:, :n]
+        exact = ops.linear(x.to(dev), w.to(dev), b.to(dev)).cpu()[:, :n]
+    else:
+        _, b_, h, w_, cin, cout = case
+        x = _rand(b_, cin, h, w_, seed=83) * 2 + 0.1
+        wt = _rand(cout, cin, 3, 3, seed=84, scale=1 / math.sqrt(cin * 9))
+        bias = _rand(cout, seed=85)
+        up = kind == "conv_up"
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+        ref = F.conv2d(xin.double(), wt.double(), bias.double(), padding=1)
+        xd = to_nhwc(x, torch.float32, dev, cpad=W.round8(cin))
+        wd = W.pack_conv(wt).to(dev)
+        with ops.f32_gemm_mode("x3"):
+            got = from_nhwc(ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, upsample=up), cout)
+        exact = from_nhwc(ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, upsample=up), cout)
+    scale = ref.abs().max().item()
+    e3 = (got.double() - ref).abs().max().item() / scale
+    ee = (exact.double() - ref).abs().max().item() / scale
+    print(f"f32x3 {case}: max err / max|ref| = {e3:.2e} (exact fp32 path {ee:.2e})")
+    assert ee < 2e-6 and e3 < 4e-5, (e3, ee)

@@ -117,6 +117,22 @@ def test_vae_decode_tiny(dev, tiny, dtype):
     assert _relerr(got, ref) < _limits(dtype), _relerr(got, ref)
 
 
+def test_vae_decode_f32x3(dev):
+    """The upcast SDXL VAE's default arithmetic (fp32 storage, SASPA_F32X3 GEMMs) at full SDXL-VAE width, 64x64 image:
+    per-pixel error against the oracle far inside the 1e-3 bar."""
+    cfg = CFG.SDXL_TURBO["vae"]
+    sd = W.synth_state_dict("vae", cfg, 4)
+    z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(13))
+    ref = OM.vae_decode(sd, cfg, z)
+    e = {}
+    for mode in ("exact", "x3"):
+        vae = models.VAEDecoder(sd, cfg, dev, torch.float32, f32_gemm=mode)
+        got = from_nhwc(vae.decode(to_nhwc(z, torch.float32, dev, cpad=8)), 3)
+        e[mode] = ((got / 2 + 0.5).clamp(0, 1) - (ref / 2 + 0.5).clamp(0, 1)).abs().max().item()
+    print(f"fp32 VAE decode vs oracle, max |d| on [0,1]: exact {e['exact']:.2e}, x3 {e['x3']:.2e}")
+    assert e["exact"] < 2e-5 and e["x3"] < 2e-4, e
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_unet_controlnet_full_width_step(dev, dtype):
     """One SD-v1.5 + ControlNet evaluation at full width (859.5 M + 361.3 M parameters),

@@ -93,7 +93,7 @@ def cpu_baseline(seconds_budget=15.0):
     repeated UNet+ControlNet CFG evaluations of one 512x512 image (each 2.167 TFLOP incl. the
     conditioning embedding the un-hoisted oracle recomputes) until ~seconds_budget of CPU work;
     EXTRAPOLATED by FLOPs to one 50-step image (109.33 TFLOP).  The directly timed BASELINE configs[0] run
-    (1 image, 10 steps, whole pipeline) is `--baselines full` -> profiles/r2_baselines_full.json."""
+    (1 image, 10 steps, whole pipeline) is `--baselines full` -> profiles/r2_bench_line_v0_with_baselines_full.json."""
     import torch
 
     from oracle import sd_models as OM
@@ -389,7 +389,7 @@ def run(args):
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         roof = dict(bound="mfma",
                     kernel="implicit-GEMM conv / linear family: gemm_dma_kernel (LDS-DMA 128x160 / 128x128 tiles), gemm_pp_kernel "
-                           "(8-wave 256x320 / 256x256), gemm_as_kernel (A-stationary short-K linears); v_mfma_f32_16x16x32_bf16",
+                           "(8-wave 256x320 / 256x256), gemm_ws_kernel (12-wave wave-specialised 128x160, one-wave tile counts); v_mfma_f32_16x16x32_bf16",
                     achieved=round(achieved, 1), peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / BF16_PEAK_TFLOPS, 4), traffic=None,
                     launches=gm["launches"], avg_launch_us=round(gm["ms"] * 1e3 / gm["launches"], 2),

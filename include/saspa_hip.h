@@ -56,7 +56,7 @@ extern "C" {
 #define SASPA_GEMM_AUTO 0
 #define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
 #define SASPA_GEMM_WIDE 2  /* 8-wave 256x320 / 256x256 tile, one workgroup per CU */
-#define SASPA_GEMM_WS 3    /* wave-specialised 128x160 tile (4 MMA waves + 4 loader / epilogue waves): short-K bf16 layers */
+#define SASPA_GEMM_WS 3    /* wave-specialised 128x160 tile (12 waves: 4 MMA + 4 loader + 4 epilogue): short-K bf16 layers */
 
 #define SASPA_KORDER_TAP 0
 #define SASPA_KORDER_CHUNK 1
@@ -106,8 +106,8 @@ typedef struct SaspaGemmParams {
   float* workspace;
   /* kernel variant: SASPA_GEMM_AUTO lets the library choose per shape; the other values pin one
    * (tests, tuning).  SASPA_GEMM_WIDE = one 8-wave workgroup per CU on a 256 x 256/320 tile
-   * (long-K bf16 layers); it returns SASPA_ERANGE for a problem it cannot run (fp32, fused
-   * GEGLU, channel counts that are not multiples of 64, windows other than 1x1 or 3x3/pad 1). */
+   * (long-K bf16 layers); it returns SASPA_ERANGE for a problem it cannot run (fp32, fused GEGLU
+   * unless N % 320 == 0, channel counts that are not multiples of 64, windows other than 1x1 or 3x3/pad 1). */
   int variant;
   /* K order of the packed weights (and of the K walk), ABI v4.  SASPA_KORDER_TAP: K = (ky*kw+kx)*C + c (tap-major, the
    * default).  SASPA_KORDER_CHUNK: the C = c0+c1 channels are cut into chunks of one K-tile (64 bf16 / 32 fp32 elements)
@@ -148,8 +148,9 @@ int saspa_softmax_rows(int dtype, void* x, long long rows, int n, int ld, float 
                        int causal, int rows_per_mat, void* stream);
 
 /* ---- GroupNorm (+SiLU): NHWC, two launches -------------------------------
- * stats: per (batch, channel) sums -> per (batch, group) mean/rstd folded with
- * gamma/beta into scale/shift[b][c];  apply: y = act(x*scale + shift).
+ * stats: per (image, pixel split, channel slab, group) sums of x and x^2 into `partial`;
+ * apply: every workgroup first combines the sums of ITS image in fp64 into mean / rstd per group (no
+ * finalize launch in between, ABI 10), then streams y = act((x - mean) * rstd * gamma + beta).
  * Replaces ResnetBlock2D.norm1/norm2 (+SiLU), Transformer2DModel.norm, conv_norm_out,
  * VAE GroupNorms (a7.5, a7.6, a7.8).
  * x may be the channel concat of two sources (x1 != NULL). */

@@ -101,10 +101,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
       const int g = g0 + (tid >> 3);
       double sm = 0.0, sq = 0.0;
       if (g < p.groups) {
-        for (int i = sub; i < nparts; i += 8) {
-          const float2 v = *reinterpret_cast<const float2*>(base + ((long long)i * p.groups + g) * 2);
-          sm += (double)v.x;
-          sq += (double)v.y;
+        // 8 loads in flight per thread and round (64 partial sums per group and round): one L2 round trip for the usual
+        // nsplit * slabs <= 64, instead of one per element
+        for (int i0 = sub; i0 < nparts; i0 += 64) {
+          float2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 8 * u;
+            v[u] = make_float2(0.f, 0.f);
+            if (i < nparts) v[u] = *reinterpret_cast<const float2*>(base + ((long long)i * p.groups + g) * 2);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            sm += (double)v[u].x;
+            sq += (double)v[u].y;
+          }
         }
       }
 #pragma unroll

@@ -289,9 +289,9 @@ def softmax_rows(x, n, scale, causal=False, rows_per_mat=1):
 
 
 def _gn_nsplit(batch, hw, c8):
-    """Pixel splits of the statistics pass: about 512 workgroups per channel slab (the apply pass re-reads
+    """Pixel splits of the statistics pass: about 1024 workgroups per channel slab (the apply pass re-reads
     nsplit * slabs * groups sums per workgroup, so no more than needed to fill the chip)."""
-    want = max(1, 512 // max(1, batch))
+    want = max(1, int(os.environ.get("SASPA_GN_BLOCKS", "1024")) // max(1, batch))
     return max(1, min(want, 64, hw // 16 if hw >= 16 else 1))
 
 

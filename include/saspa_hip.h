@@ -311,6 +311,28 @@ int saspa_resize_area_u8(const uint8_t* src, uint8_t* dst, int n, int h, int w, 
                          int isx, int isy, void* stream);
 
 /* library self-description */
+/* ---- fp8 (OCP e4m3) W8A8 linears (BASELINE.json configs[4] "fp8 MFMA") ------------------------------------
+ * saspa_layernorm_quant_fp8: LayerNorm over the last dim of bf16 x [rows][C] (C <= 2048), then per-row quantisation:
+ *   scale[r] = max|y[r][:]| / 448, q[r][c] = e4m3(y[r][c] / scale[r])      (BasicTransformerBlock.norm2 / norm3 feeding
+ *   attn2.to_q / ff.net.0.proj on the fp8 path; the normalised bf16 tensor is never written).
+ * saspa_gemm_fp8: out[m][n] = act(sa[m] * sw[n] * sum_k a[m][k] * w[n][k] + bias[n]) (+ residual[m][n]), a / w e4m3 bytes
+ *   (row pitches lda / ldw in bytes = elements, multiples of 16), K and N multiples of 128, sa per row (the quantiser's
+ *   scales), sw per output channel (weights.quantize_fp8), out / residual bf16; act = SASPA_ACT_NONE or SASPA_ACT_GEGLU
+ *   (rows of w regrouped per 128-column tile: 64 values then their 64 gates; out has N / 2 columns).  128x128 tiles on
+ *   v_mfma_f32_16x16x128_f8f6f4, fp32 accumulation. */
+typedef struct SaspaGemmF8Params {
+  const void* a; int lda;
+  const void* w; int ldw;
+  int M, N, K;
+  const float* sa; const float* sw; const float* bias;
+  const void* residual; int ldr;
+  int act;
+  void* out; int ldo;
+} SaspaGemmF8Params;
+int saspa_gemm_fp8(const SaspaGemmF8Params* p, void* stream);
+int saspa_layernorm_quant_fp8(const void* x, int ldx, void* q, int ldq, float* scale, long long rows, int C,
+                              const float* gamma, const float* beta, float eps, void* stream);
+
 /* ---- HED annotator head (run_aug/run_aug.py:311-312, :438-439 -> controlnet_aux HEDdetector.__call__) -------
  * The network's conv stack runs as saspa_gemm / saspa_pool2d launches; this is what follows it: side output k
  * ([n][mh][mw] fp32 samples at element pitch ld -- channel 0 of a channel-padded NHWC tensor) is resized to H x W like

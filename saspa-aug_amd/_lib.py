@@ -46,6 +46,14 @@ class GroupNormParams(C.Structure):
     ]
 
 
+class GemmF8Params(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("sa", C.c_void_p), ("sw", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
+        ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int),
+    ]
+
+
 class HedFuseParams(C.Structure):
     _fields_ = [
         ("nmaps", C.c_int), ("n", C.c_int), ("H", C.c_int), ("W", C.c_int),
@@ -87,6 +95,8 @@ SYMBOLS = {
     "saspa_signsqrt_l2norm": (_I, [_P, _LL, _P, _LL, _I, _LL, _F, _F, _P]),
     "saspa_resize_taps_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "saspa_hed_fuse": (_I, [C.POINTER(HedFuseParams), _P]),
+    "saspa_gemm_fp8": (_I, [C.POINTER(GemmF8Params), _P]),
+    "saspa_layernorm_quant_fp8": (_I, [_P, _I, _P, _I, _P, _LL, _I, _P, _P, _F, _P]),
     "saspa_resize_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "saspa_vae_sample_noise": (_I, [_I, _P, _P, _P, _P, _LL, _F, _F, _F, _P]),
     "saspa_cfg_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P]),

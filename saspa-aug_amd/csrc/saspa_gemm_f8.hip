@@ -1,0 +1,245 @@
+// fp8 (OCP e4m3) W8A8 linear layers for the SDXL transformer blocks (BASELINE.json configs[4]: "fp8 MFMA"):
+//   saspa_layernorm_quant_fp8   LayerNorm over the last dim -> fp8 row + one fp32 scale per row (amax / 448), one wave per row
+//   saspa_gemm_fp8              out[m][n] = act(sa[m] * sw[n] * sum_k A8[m][k] * W8[n][k] + bias[n]) (+ residual), bf16 out
+// on `v_mfma_f32_16x16x128_f8f6f4` (the K = 128 form that reaches the fp8 peak; the K = 32 `_fp8_fp8` form runs at the bf16
+// rate).  Per-token x per-channel scales are applied in the epilogue, so the K loop is byte movement + MFMA only.
+// Tile 128 x 128 x 128 bytes of K, 4 waves (2 x 2, 64 x 64 per wave), operands global -> LDS by LDS-DMA with the XOR
+// swizzle on the source side (the same 128-byte-row LDS image as the bf16 kernel: one row = ONE K = 128 MFMA step; lane
+// (row, g = lane >> 4) reads chunks 2g, 2g + 1 = its 32 k values -- both operands use the same assignment, so it is a valid
+// permutation of the sum whatever the hardware's k order inside the instruction is), 2-stage ring, one barrier per K-tile.
+// Bound: L2 -> LDS fill (32 KB per 4.2 MFLOP K-tile: 1.85x the flops per filled byte of the bf16 128x160 tile).
+#include "common.h"
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+constexpr unsigned kInvalidOff = 0x80000000u;   // beyond num_records of make_rsrc: the DMA lands zeros
+
+template <bool GEGLU>
+__global__ __launch_bounds__(256, 2) void gemm_f8_kernel(const SaspaGemmF8Params p) {
+  constexpr int BM = 128, BN = 128, STAGE = (BM + BN) * 8;   // u32x4 per stage
+  __shared__ u32x4 lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int nbn = p.N / BN;
+  // XCD-aware order: blocks congruent mod 8 (one XCD) walk neighbouring tiles (same activation rows -> same L2)
+  int tile;
+  {
+    const int G = gridDim.x, L = blockIdx.x;
+    const int qd = G >> 3, rr = G & 7, xcd = L & 7, idx = L >> 3;
+    tile = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + idx;
+  }
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const rsrc_t rsa = make_rsrc(p.a), rsw = make_rsrc(p.w);
+  const int r0 = tid >> 3;
+  const int kcs = (tid & 7) ^ (r0 & 7);
+  unsigned offa[4], offb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm * BM + r0 + 32 * i;
+    offa[i] = m < p.M ? (unsigned)((long long)m * p.lda + kcs * 16) : kInvalidOff;
+    const int n = bn * BN + r0 + 32 * i;
+    offb[i] = (unsigned)((long long)n * p.ldw + kcs * 16);
+  }
+  auto dma = [&](int kt, int stage) __attribute__((always_inline)) {
+    u32x4* la = lds + stage * STAGE;
+    u32x4* lb = la + BM * 8;
+    const int soff = kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void_t*)(la + (32 * i + 8 * wave) * 8), 16, (int)offa[i], soff, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lb + (32 * i + 8 * wave) * 8), 16, (int)offb[i], soff, 0, 0);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](const u32x4* base, int row) __attribute__((always_inline)) {
+    const u32x4 c0 = base[row * 8 + ((2 * fg) ^ (row & 7))];
+    const u32x4 c1 = base[row * 8 + ((2 * fg + 1) ^ (row & 7))];
+    return i32x8{(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], (int)c1[2], (int)c1[3]};
+  };
+  const int nk = p.K / 128;
+  dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // K-tile kt has landed for everyone; the other stage is free
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);                // issue the DMA before the MFMA block so that it flies under it
+    const u32x4* la = lds + (kt & 1) * STAGE;
+    const u32x4* lb = la + BM * 8;
+    i32x8 xa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = frag(la, wm * 64 + i * 16 + frow);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const i32x8 wb = frag(lb, wn * 64 + j * 16 + frow);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        // D^T: weights as the A operand, so a lane owns 4 consecutive output channels of one row; formats 0 / 0 = e4m3,
+        // scale exponents 127 = 1.0 (E8M0) in byte 0 of both scale operands
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wb, xa[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: scales + bias, tile through LDS, whole-row 16-byte stores (GEGLU pairs values / gates there) ----
+  constexpr int CP = BN + 8;
+  bf16_t* ct = reinterpret_cast<bf16_t*>(lds);
+  float4 sw4[4], b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = bn * BN + wn * 64 + j * 16 + fg * 4;
+    sw4[j] = *reinterpret_cast<const float4*>(p.sw + n);
+    b4[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mrow = wm * 64 + i * 16 + frow;
+    const int m = bm * BM + mrow;
+    const float sa = m < p.M ? p.sa[m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ncol = wn * 64 + j * 16 + fg * 4;
+      const float v[4] = {acc[i][j][0] * (sa * sw4[j].x) + b4[j].x, acc[i][j][1] * (sa * sw4[j].y) + b4[j].y,
+                          acc[i][j][2] * (sa * sw4[j].z) + b4[j].z, acc[i][j][3] * (sa * sw4[j].w) + b4[j].w};
+      Elem<bf16_t>::store4(ct + mrow * CP + ncol, v);
+    }
+  }
+  __syncthreads();
+  bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+  if constexpr (GEGLU) {
+    // tile columns [0, 64) are values, [64, 128) their gates (weights.pack_geglu with a 128-column tile)
+    for (int q = tid; q < BM * 8; q += 256) {
+      const int row = q >> 3, ch = q & 7;
+      const int m = bm * BM + row;
+      if (m >= p.M) continue;
+      float a[8], g[8];
+      unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + ch * 8), a);
+      unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + 64 + ch * 8), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = fast_gelu_mul(a[e], g[e]);
+      *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + bn * 64 + ch * 8) = pack8(a);
+    }
+  } else {
+    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
+    for (int q = tid; q < BM * 16; q += 256) {
+      const int row = q >> 4, ch = q & 15;
+      const int m = bm * BM + row, n = bn * BN + ch * 8;
+      if (m >= p.M) continue;
+      uint4 c4 = *reinterpret_cast<const uint4*>(ct + row * CP + ch * 8);
+      if (res) {
+        float a[8], b[8];
+        unpack8(c4, a);
+        Elem<bf16_t>::load_chunk(res + (long long)m * p.ldr + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        c4 = pack8(a);
+      }
+      *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + n) = c4;
+    }
+  }
+}
+
+// LayerNorm + per-row fp8 quantisation: one wave per row, the row stays in registers (C <= 2048).
+__global__ __launch_bounds__(256) void layernorm_quant_fp8_kernel(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, long long rows,
+                                                                  int C, const float* gamma, const float* beta, float eps) {
+  constexpr int MAXCH = 4;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C8 = C >> 3;
+  const bf16_t* xr = x + row * ldx;
+  float v[MAXCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int chunk = lane + 64 * i;
+    if (chunk < C8) {
+      Elem<bf16_t>::load_chunk(xr + chunk * 8, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int chunk = lane + 64 * i;
+    if (chunk < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int chunk = lane + 64 * i;
+    if (chunk < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = (v[i][j] - mean) * rstd * gamma[chunk * 8 + j] + beta[chunk * 8 + j];
+        amax = fmaxf(amax, fabsf(v[i][j]));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;     // e4m3 maximum 448
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  uint8_t* qr = q + row * ldq;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int chunk = lane + 64 * i;
+    if (chunk < C8) {
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, w1, true);
+      *reinterpret_cast<int2*>(qr + chunk * 8) = make_int2(w0, w1);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int saspa_layernorm_quant_fp8(const void* x, int ldx, void* q, int ldq, float* scale, long long rows, int C,
+                                         const float* gamma, const float* beta, float eps, void* stream) {
+  if (!x || !q || !scale || !gamma || !beta || rows <= 0 || C <= 0) return SASPA_EINVAL;
+  if (C % 8 || ldx % 8 || ldq % 8 || !aligned16(x) || (reinterpret_cast<uintptr_t>(q) & 7u)) return SASPA_EALIGN;
+  if (C > 2048 || ldq < C || ldx < C) return SASPA_ERANGE;
+  hipLaunchKernelGGL(layernorm_quant_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, rows, C, gamma, beta, eps);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_gemm_fp8(const SaspaGemmF8Params* pp, void* stream) {
+  if (!pp) return SASPA_EINVAL;
+  const SaspaGemmF8Params& p = *pp;
+  if (!p.a || !p.w || !p.sa || !p.sw || !p.out || p.M <= 0 || p.N <= 0 || p.K <= 0) return SASPA_EINVAL;
+  if (p.act != SASPA_ACT_NONE && p.act != SASPA_ACT_GEGLU) return SASPA_EINVAL;
+  if (p.K % 128 || p.N % 128) return SASPA_ERANGE;                 // whole K-tiles and output tiles
+  if (p.lda < p.K || p.ldw < p.K || p.lda % 16 || p.ldw % 16) return SASPA_EALIGN;
+  if (!aligned16(p.a) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.sw) || (p.bias && !aligned16(p.bias))) return SASPA_EALIGN;
+  if (p.ldo % 8 || p.ldo < (p.act == SASPA_ACT_GEGLU ? p.N / 2 : p.N)) return SASPA_EALIGN;
+  if (p.act == SASPA_ACT_GEGLU && p.residual) return SASPA_ERANGE;
+  if (p.residual && (p.ldr % 8 || !aligned16(p.residual))) return SASPA_EALIGN;
+  if ((long long)p.M * p.lda >= (1ll << 31) || (long long)p.N * p.ldw >= (1ll << 31)) return SASPA_ERANGE;   // 32-bit DMA offsets
+  const int tiles = ((p.M + 127) / 128) * (p.N / 128);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.act == SASPA_ACT_GEGLU) hipLaunchKernelGGL(gemm_f8_kernel<true>, dim3(tiles), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gemm_f8_kernel<false>, dim3(tiles), dim3(256), 0, s, p);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}

@@ -130,8 +130,12 @@ def attention_core(q, k, vt, heads, nq, nk, causal=False):
 # UNet / ControlNet building blocks
 # ------------------------------------------------------------------------------------------
 class _Net:
-    def __init__(self, sd, cfg, dev, dtype):
+    def __init__(self, sd, cfg, dev, dtype, fp8=False):
         self.cfg, self.dev, self.dtype = cfg, dev, dtype
+        # fp8: the LayerNorm-fed projections of the transformer blocks (attn2.to_q, ff.net.0.proj) run W8A8 on
+        # saspa_gemm_fp8 (bf16 networks only; blocks whose width is not a multiple of 128 stay bf16)
+        self.fp8 = bool(fp8) and dtype == torch.bfloat16
+        self.fp8_blocks = set()
         self.pk = _Packed(sd, dev, dtype)
         self.p = self.pk.p
         self.temb_tables = {}
@@ -175,6 +179,8 @@ class _Net:
             else:
                 pk.linear(t + ".ff.net.0.proj")
             pk.linear(t + ".ff.net.2")
+            if self.fp8 and pk.sd[t + ".norm2.weight"].numel() % 128 == 0:
+                self._quantize_block(t)
             self.blocks.append(t)
         pk.conv(pfx + ".proj_out")
         self.tr_info[pfx] = (heads, depth)
@@ -287,6 +293,18 @@ class _Net:
             sc = x
         return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
 
+    def _quantize_block(self, t):
+        """e4m3 copies (per-output-channel scales) of the two projections that read a LayerNorm's output; the GEGLU
+        projection's rows are regrouped for the fp8 kernel's 128-column tiles."""
+        sd, p = self.pk.sd, self.p
+        wq, sw = W.quantize_fp8(sd[t + ".attn2.to_q.weight"])
+        p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"] = wq.to(self.dev), sw.to(self.dev)
+        wg, bg = W.pack_geglu_tile(sd[t + ".ff.net.0.proj.weight"].float(), sd[t + ".ff.net.0.proj.bias"].float(), 128)
+        wq, sw = W.quantize_fp8(wg)
+        p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"] = wq.to(self.dev), sw.to(self.dev), _f32(bg, self.dev)
+        del p[t + ".attn2.q.w"], p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]
+        self.fp8_blocks.add(t)
+
     def transformer(self, pfx, x):
         p, g = self.p, self.cfg["groups"]
         heads, depth = self.tr_info[pfx]
@@ -302,6 +320,18 @@ class _Net:
             vt = project_vt(n1, p[t + ".attn1.v.w"], n)
             o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n)
             h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
+            if t in self.fp8_blocks:
+                # W8A8: LayerNorm + per-token quantisation in one pass, e4m3 x e4m3 MFMA, scales applied in the epilogue
+                q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
+                q = ops.linear_fp8(q8, s8, p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"])
+                k, vtc, nk = self.ctx_kv[t]
+                o = attention_core(q, k, vtc, heads, n, nk)
+                h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
+                q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
+                ff = ops.linear_fp8(q8, s8, p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"],
+                                    act=ops.ACT_GEGLU)
+                h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
+                continue
             # cross-attention against the cached text K / V^T
             n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
             q = ops.linear(n2, p[t + ".attn2.q.w"])
@@ -342,8 +372,8 @@ class _Net:
 class UNet(_Net):
     """UNet2DConditionModel (SD-1.5 topology)."""
 
-    def __init__(self, sd, cfg, dev, dtype):
-        super().__init__(sd, cfg, dev, dtype)
+    def __init__(self, sd, cfg, dev, dtype, fp8=False):
+        super().__init__(sd, cfg, dev, dtype, fp8)
         self._pack_encoder()
         pk = self.pk
         bo = cfg["block_out"]
@@ -396,8 +426,8 @@ class UNet(_Net):
 class ControlNet(_Net):
     """ControlNetModel (control_v11p_sd15_canny topology)."""
 
-    def __init__(self, sd, cfg, dev, dtype):
-        super().__init__(sd, cfg, dev, dtype)
+    def __init__(self, sd, cfg, dev, dtype, fp8=False):
+        super().__init__(sd, cfg, dev, dtype, fp8)
         self._pack_encoder()
         pk = self.pk
         ce = cfg["cond_embed"]

@@ -342,6 +342,42 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
+def layernorm_quant_fp8(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the last dim of bf16 x, quantised per row to e4m3 -> (q uint8 [..., C], scale fp32 [rows])."""
+    _check_dev(x, gamma, beta)
+    if x.dtype != torch.bfloat16:
+        raise TypeError("the fp8 path takes bf16 activations")
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c)
+    rows = x2.shape[0]
+    q = torch.empty((rows, c), device=x.device, dtype=torch.uint8)
+    scale = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().saspa_layernorm_quant_fp8(_ptr(x2), x2.stride(0) if rows > 1 else c, _ptr(q), c, _ptr(scale), rows, c,
+                                                     _ptr(gamma), _ptr(beta), float(eps), _stream()), "saspa_layernorm_quant_fp8")
+    return q.view(*x.shape[:-1], c), scale
+
+
+def linear_fp8(xq, xscale, wq, wscale, bias=None, *, residual=None, act=ACT_NONE):
+    """e4m3 activations (uint8 [..., K] + per-row scale) @ e4m3 weights (uint8 [N, K] + per-channel scale)^T -> bf16
+    [..., N] (N / 2 with the fused GEGLU): `saspa_gemm_fp8`."""
+    _check_dev(xq, xscale, wq, wscale, bias, residual)
+    k = xq.shape[-1]
+    x2 = xq.reshape(-1, k)
+    m, n = x2.shape[0], wq.shape[0]
+    nout = n // 2 if act == ACT_GEGLU else n
+    out = torch.empty((m, nout), device=xq.device, dtype=torch.bfloat16)
+    r2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+    p = _lib.GemmF8Params()
+    p.a, p.lda, p.w, p.ldw = _ptr(x2), x2.stride(0) if m > 1 else k, _ptr(wq), wq.stride(0)
+    p.M, p.N, p.K = m, n, k
+    p.sa, p.sw, p.bias = _ptr(xscale), _ptr(wscale), _ptr(bias)
+    p.residual, p.ldr = _ptr(r2), 0 if r2 is None else r2.stride(0)
+    p.act, p.out, p.ldo = int(act), _ptr(out), nout
+    _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(_lib.load().saspa_gemm_fp8(C.byref(p), _stream()), "saspa_gemm_fp8"),
+            (m, n, k, 0, 1, 0, False))
+    return out.reshape(*xq.shape[:-1], nout)
+
+
 def geglu(x, out=None):
     """x: [..., 2F] -> [..., F] = x[..., :F] * gelu_erf(x[..., F:])"""
     _check_dev(x, out)

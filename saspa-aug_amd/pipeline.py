@@ -243,8 +243,9 @@ class StableDiffusionControlNetPipeline:
         torch.cuda.set_device(device)
         self.device = device
         sd, cf = self._state_dicts, self.cfgs
-        self.unet = models.UNet(sd["unet"], cf["unet"], device, cdt)
-        self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt)
+        fp8 = getattr(self, "_fp8", False) or os.environ.get("SASPA_FP8", "0") == "1"
+        self.unet = models.UNet(sd["unet"], cf["unet"], device, cdt, fp8=fp8)
+        self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt, fp8=fp8)
         self.vae = models.VAEDecoder(sd["vae"], cf["vae"], device, cdt)
         self.text_encoder = models.CLIPText(sd["text"], cf["text"], device, cdt)
         self._build_extra(sd, cf, device, cdt)
@@ -256,6 +257,15 @@ class StableDiffusionControlNetPipeline:
         # StableDiffusionSafetyChecker of the SD-1.5 repo: the reference never passes safety_checker=None
         if "safety" in sd and "safety" in cf:
             self.safety_checker = models.SafetyChecker(sd["safety"], cf["safety"], device, cdt)
+
+    def enable_fp8(self, on=True):
+        """Call BEFORE `.to()`: the LayerNorm-fed projections of the UNet / ControlNet transformer blocks (cross-attention
+        query, GEGLU feed-forward) run as e4m3 W8A8 GEMMs (BASELINE.json configs[4] "fp8 MFMA"; SASPA_FP8=1 does the same).
+        Off by default: the headline metric is quoted in bf16."""
+        if self.unet is not None:
+            raise RuntimeError("enable_fp8() must be called before .to(): the weights are quantised at pack time")
+        self._fp8 = bool(on)
+        return self
 
     def upcast_vae(self, gemm=None):  # SDXL-only hook the reference calls at run_aug/run_aug.py:224
         return self

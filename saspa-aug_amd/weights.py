@@ -529,6 +529,34 @@ def pack_linear(w, k_pad=None):
     return w.contiguous()
 
 
+def quantize_fp8(w):
+    """[N, K] fp32 weight -> (e4m3 bytes as uint8 [N, K], per-output-channel scale fp32 [N]) with w ~ q * scale[:, None]
+    (scale = row amax / 448, OCP e4m3fn as the gfx950 MFMA reads it)."""
+    w = w.float()
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def dequantize_fp8(q_u8, scale):
+    return q_u8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def pack_geglu_tile(w, b, bn):
+    """pack_geglu with an explicit tile width (the fp8 kernel's tiles are 128 columns: 64 values then their 64 gates)."""
+    n = w.shape[0]
+    f = n // 2
+    if n % bn:
+        return None
+    half = bn // 2
+    idx = []
+    for t in range(n // bn):
+        idx += list(range(t * half, (t + 1) * half)) + list(range(f + t * half, f + (t + 1) * half))
+    idx = torch.tensor(idx)
+    return w[idx].contiguous(), b[idx].contiguous()
+
+
 def geglu_tile(n):
     """Output-tile width the GEMM picks for N columns (must mirror csrc/saspa_gemm.hip)."""
     return 160 if n % 160 == 0 else 128

@@ -1,7 +1,7 @@
 """BASELINE.json configs[4] timing (parity-test configuration, not the bench line): SDXL-Turbo + Canny ControlNet at
 full width, synthetic weights, bf16 denoiser + fp32-upcast VAE (run_aug/run_aug.py:224).  Two operating points:
 the reference's own (512x512, 2 DDIM steps, no CFG, run_aug/run_aug.py:564-571) and the BASELINE stretch shape
-(1024x1024, 4 steps).  usage: python tools/sdxl_bench.py [batch] [--bf16-vae | --exact-vae]"""
+(1024x1024, 4 steps).  usage: python tools/sdxl_bench.py [batch] [--bf16-vae | --exact-vae] [--fp8]"""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -13,6 +13,8 @@ dev = torch.device('cuda:0')
 b = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 t0 = time.time()
 pipe = StableDiffusionXLControlNetPipeline.from_synthetic(CFG.SDXL_TURBO, 0)
+if "--fp8" in sys.argv:
+    pipe.enable_fp8()
 if "--bf16-vae" not in sys.argv:
     pipe.upcast_vae("exact" if "--exact-vae" in sys.argv else None)      # default: fp32 storage, SASPA_F32X3 GEMMs
 pipe = pipe.to(dev, torch.bfloat16)
@@ -39,4 +41,4 @@ for res, steps in ((512, 2), (1024, 4)):
     print(json.dumps({"workload": f"SDXL-Turbo + Canny ControlNet, batch={b} {res}x{res}, {steps} DDIM steps, no CFG, ctrl-scale 0.75",
                       "images_per_s": round(b / dt, 3), "s_per_batch": round(dt, 3), "vae_decode_s_per_batch": round(tv, 3),
                       "vae_dtype": str(pipe.vae.dtype).replace("torch.", ""), "vae_gemm": pipe.vae.f32_gemm, "deterministic": bool(torch.equal(out, out2)),
-                      "finite": bool(out.float().isfinite().all()), "dtype": "bf16", "data": "synthetic"}), flush=True)
+                      "finite": bool(out.float().isfinite().all()), "dtype": "bf16 + fp8 (e4m3 W8A8) transformer projections" if "--fp8" in sys.argv else "bf16", "data": "synthetic"}), flush=True)

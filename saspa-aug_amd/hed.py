@@ -67,7 +67,7 @@ class HEDdetector:
         f = os.path.join(path, filename)
         if not os.path.exists(f):
             raise FileNotFoundError(f"{f}: the HED annotator checkpoint must be on local disk")
-        return cls(torch.load(f, map_location="cpu"), HED, device)
+        return cls(torch.load(f, map_location="cpu", weights_only=True), HED, device)
 
     def _pack(self, name, sd):
         w = sd[name + ".weight"].float()

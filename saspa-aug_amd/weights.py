@@ -395,11 +395,59 @@ def openai_clip_text_to_hf(sd, layers):
     return out
 
 
+_BIG = 1 << 20          # elements: tensors at least this large are drawn chunk-wise on a thread pool
+_BIG_EXEMPT = ("cal", "clip_rn50", "hed")     # kinds whose tensors stay on the sequential stream: reference goldens
+                                              # (tests/golden/reference_filter_golden.json) were made from them
+_BIG_SCALE = {"w": None, "pos": None, "wt": None, "w_fc": 0.05, "embed": 0.5}
+
+
+def _fill_big(pending, seed):
+    """Draw every large tensor of a state dict: rows are cut into chunks of <= 1 M elements, each from its own generator
+    seeded by (state-dict seed, tensor index, chunk index), ALL chunks of all tensors on one thread pool -- torch's seeded
+    CPU generator is serial (~30 M values/s), which made synthesising the 4.7 B parameters of the SDXL family take 100 s."""
+    import concurrent.futures as cf
+    import os
+    jobs = []
+    for index, t, scale in pending:
+        flat = t.view(t.shape[0], -1)
+        rows = max(1, (1 << 20) // max(1, flat.shape[1]))
+        for j, r0 in enumerate(range(0, t.shape[0], rows)):
+            jobs.append((flat, r0, min(t.shape[0], r0 + rows), (seed * 1000003 + index * 7919 + j * 104729 + 12345) & 0x7FFFFFFF, scale))
+
+    def draw(job):
+        flat, r0, r1, sd_, scale = job
+        gj = torch.Generator().manual_seed(sd_)
+        flat[r0:r1] = torch.randn((r1 - r0, flat.shape[1]), generator=gj) * scale
+
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 4)))) as ex:
+        list(ex.map(draw, jobs, chunksize=1))
+
+
 def synth_state_dict(kind, cfg, seed=0):
     """Seeded synthetic fp32 state dict with diffusers key names."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    for name, shape, k in SPECS[kind](cfg):
+    pending = []          # large tensors: allocated here, filled in parallel at the end
+    for index, (name, shape, k) in enumerate(SPECS[kind](cfg)):
+        numel = 1
+        for d in shape:
+            numel *= d
+        if numel >= _BIG and k in _BIG_SCALE and len(shape) >= 2 and kind not in _BIG_EXEMPT:
+            if k == "w":
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                scale = 1.0 / math.sqrt(fan_in)
+            elif k == "pos":
+                scale = 1.0 / math.sqrt(shape[-1])
+            elif k == "wt":
+                scale = 1.0 / math.sqrt(shape[0])
+            else:
+                scale = _BIG_SCALE[k]
+            t = torch.empty(tuple(shape), dtype=torch.float32)
+            pending.append((index, t, scale))
+            sd[name] = t
+            continue
         if k == "w":
             fan_in = 1
             for s in shape[1:]:
@@ -428,6 +476,8 @@ def synth_state_dict(kind, cfg, seed=0):
         else:  # embeddings
             t = 0.5 * torch.randn(shape, generator=g)
         sd[name] = t
+    if pending:
+        _fill_big(pending, seed)
     return sd
 
 

@@ -59,7 +59,8 @@ def test_clip_text_full_width(dev, dtype):
     assert _relerr(got, ref) < _limits(dtype), _relerr(got, ref)
 
 
-def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w, steps=4, step=1):
+def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w, steps=4, step=1, cache=None):
+    """cache: a dict shared by the dtype variants of one (family, shape) -- the CPU oracle evaluation is computed once."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(b, 4, h, w, generator=g)
     ctx = torch.randn(b, 77, cfgs["unet"]["ctx_dim"], generator=g)
@@ -67,9 +68,14 @@ def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w, steps=4, step=1):
     sch = OP.DDIM()
     ts = sch.set_timesteps(steps)
     t = int(ts[step])
-    down, mid = OM.controlnet_forward(fam["controlnet"], cfgs["controlnet"], x, t, ctx, cond, 0.75)
-    ref = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx, down, mid)
-    ref_plain = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx)
+    if cache is not None and "ref" in cache:
+        down, mid, ref, ref_plain = cache["down"], cache["mid"], cache["ref"], cache["ref_plain"]
+    else:
+        down, mid = OM.controlnet_forward(fam["controlnet"], cfgs["controlnet"], x, t, ctx, cond, 0.75)
+        ref = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx, down, mid)
+        ref_plain = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx)
+        if cache is not None:
+            cache.update(down=down, mid=mid, ref=ref, ref_plain=ref_plain)
 
     unet = models.UNet(fam["unet"], cfgs["unet"], dev, dtype)
     cn = models.ControlNet(fam["controlnet"], cfgs["controlnet"], dev, dtype)
@@ -133,13 +139,22 @@ def test_vae_decode_f32x3(dev):
     assert e["exact"] < 2e-5 and e["x3"] < 2e-4, e
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_unet_controlnet_full_width_step(dev, dtype):
-    """One SD-v1.5 + ControlNet evaluation at full width (859.5 M + 361.3 M parameters),
-    128x128 image (16x16 latents), CFG batch 2 -- every real channel count / head dim."""
+@pytest.fixture(scope="module")
+def full_sd15_nets():
     cfgs = CFG.SD15
     fam = dict(unet=W.synth_state_dict("unet", cfgs["unet"], 0), controlnet=W.synth_state_dict("controlnet", cfgs["controlnet"], 1))
-    e = _unet_cn_case(cfgs, fam, dev, dtype, 2, 16, 16)
+    cache = {}
+    yield cfgs, fam, cache
+    fam.clear()
+    cache.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_controlnet_full_width_step(dev, full_sd15_nets, dtype):
+    """One SD-v1.5 + ControlNet evaluation at full width (859.5 M + 361.3 M parameters),
+    128x128 image (16x16 latents), CFG batch 2 -- every real channel count / head dim."""
+    cfgs, fam, cache = full_sd15_nets
+    e = _unet_cn_case(cfgs, fam, dev, dtype, 2, 16, 16, cache=cache)
     print(f"full-width UNet+ControlNet step {dtype}: max-rel errors {e}")
     assert max(e) < (1e-5 if dtype == torch.float32 else 3.5e-2), e      # 2x the measured 3.5e-6 / 1.74e-2 (r2)
 

@@ -128,7 +128,7 @@ def test_bf16_vs_fp32_hip_batch8_50_steps(dev, prod, p32):
     got01 = _img01(img)
     assert torch.isfinite(got01).all()
     psnrs, dmax, lat_rms = [], [], []
-    for i in (0, 3, 7):           # fp32 runs one image at a time (its unfused attention scores are 1 GiB per image)
+    for i in (0, 7):              # fp32 runs one image at a time (its unfused attention scores are 1 GiB per image)
         o32, x32, i32 = p32.generate_batch(prod["ids"][i:i + 1], prod["neg"], prod["ctrls"][i:i + 1], prod["lat"][i:i + 1].float(),
                                            steps, return_latents=True)
         r01 = _img01(i32)
@@ -162,7 +162,7 @@ def test_batch8_vs_single_items_full_width(dev, prod, p32):
     out, x, img = pipe.generate_batch(prod["ids"], prod["neg"], prod["ctrls"], prod["lat"], steps, return_latents=True)
     out, x = out.clone(), x.clone()
     exact, diff, e8, e1, du8 = [], [], [], [], []
-    for i in (0, 2, 5, 7):
+    for i in (0, 5):
         sl = slice(i, i + 1)
         o1, x1, _ = pipe.generate_batch(prod["ids"][sl], prod["neg"], prod["ctrls"][sl], prod["lat"][sl], steps, return_latents=True)
         x1, o1 = x1.clone(), o1.clone()

@@ -85,7 +85,7 @@ def test_img2img_pipeline_fp32_parity(dev, tiny, graph, monkeypatch):
     cfgs, fam = tiny
     assert StableDiffusionControlNetImg2ImgPipeline.kept_steps(10, 0.85) == (2, 8)
     assert StableDiffusionControlNetImg2ImgPipeline.kept_steps(30, 0.85) == (5, 25)
-    for steps, strength in ((10, 0.85), (10, 0.5)):
+    for steps, strength in (((10, 0.85), (10, 0.5)) if graph == "1" else ((10, 0.85),)):
         d01, du8, _ = _case(cfgs, fam, dev, torch.float32, steps, strength)
         assert d01 < 1e-3 and du8 <= 1, (steps, strength, d01, du8)
 

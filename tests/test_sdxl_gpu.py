@@ -75,7 +75,8 @@ def test_pad_ids_2_matches_tokenizer_2_padding(tiny_xl):
     assert np.array_equal(pipe.pad_ids_2(ids1), ids2)
 
 
-def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w):
+def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w, cache=None):
+    """cache: a dict shared by the dtype variants of one (family, shape) -- the CPU oracle evaluation is computed once."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(b, 4, h, w, generator=g)
     ctx = torch.randn(b, 77, cfgs["unet"]["ctx_dim"], generator=g)
@@ -86,8 +87,13 @@ def _unet_cn_case(cfgs, fam, dev, dtype, b, h, w):
     ts = OP.DDIM(spacing="trailing").set_timesteps(2)
     step = 1
     t = int(ts[step])
-    down, mid = OM.controlnet_forward(fam["controlnet"], cfgs["controlnet"], x, t, ctx, cond, 0.75, added)
-    ref = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx, down, mid, added)
+    if cache is not None and "ref" in cache:
+        down, mid, ref = cache["down"], cache["mid"], cache["ref"]
+    else:
+        down, mid = OM.controlnet_forward(fam["controlnet"], cfgs["controlnet"], x, t, ctx, cond, 0.75, added)
+        ref = OM.unet_forward(fam["unet"], cfgs["unet"], x, t, ctx, down, mid, added)
+        if cache is not None:
+            cache.update(down=down, mid=mid, ref=ref)
     unet = models.UNet(fam["unet"], cfgs["unet"], dev, dtype)
     cn = models.ControlNet(fam["controlnet"], cfgs["controlnet"], dev, dtype)
     assert cn.n_skips == len(down)
@@ -212,11 +218,22 @@ def test_sdxl_call_form_and_init_pipeline(dev, tiny_xl):
     assert c.size == (96, 64) and not np.array_equal(np.asarray(c), np.asarray(b))      # guidance changes the image
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_sdxl_full_width_step(dev, dtype):
-    """One SDXL UNet (2.57 B parameters) + ControlNet (1.25 B) evaluation at full width on a 128x128 image (16x16
-    latents): every real channel count, head dim 64 with 5/10/20 heads, transformer depths 2 and 10, 2048-wide context."""
+@pytest.fixture(scope="module")
+def full_xl():
+    """Full-width SDXL UNet + ControlNet state dicts (3.8 B parameters, ~40 s to synthesise) and the oracle's evaluation,
+    shared by the dtype variants; released at the end of the module."""
     cfgs = CFG.SDXL_TURBO
     fam = dict(unet=W.synth_state_dict("unet", cfgs["unet"], 0), controlnet=W.synth_state_dict("controlnet", cfgs["controlnet"], 1))
-    e = _unet_cn_case(cfgs, fam, dev, dtype, 1, 16, 16)
+    cache = {}
+    yield cfgs, fam, cache
+    fam.clear()
+    cache.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sdxl_full_width_step(dev, full_xl, dtype):
+    """One SDXL UNet (2.57 B parameters) + ControlNet (1.25 B) evaluation at full width on a 128x128 image (16x16
+    latents): every real channel count, head dim 64 with 5/10/20 heads, transformer depths 2 and 10, 2048-wide context."""
+    cfgs, fam, cache = full_xl
+    e = _unet_cn_case(cfgs, fam, dev, dtype, 1, 16, 16, cache=cache)
     assert max(e) < (1e-3 if dtype == torch.float32 else 0.12), e

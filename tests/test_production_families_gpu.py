@@ -57,8 +57,8 @@ def test_blip_full_width_bf16_graph_vs_oracle(dev, heavy_budget):
     psnr, d01, rms = _metrics(img[:1], x[:1], ref_img, ref_x)
     print(f"\n[production BLIP] bf16+graph batch {b} vs oracle, {steps} PLMS steps, image 0: subject tokens max-rel {q_rel:.3e}; "
           f"latents rms-rel {rms:.3e}; image max|d| {d01:.4f} PSNR {psnr:.1f} dB")
-    # measured r2: q_rel 1.20e-2, rms 1.56e-2, PSNR 43.3 dB
-    assert q_rel < 2.4e-2 and rms < 3.2e-2 and psnr > 37.3, (q_rel, rms, d01, psnr)
+    # measured r2 (current synthetic weights): q_rel 1.13e-2, rms 2.46e-2, PSNR 44.0 dB
+    assert q_rel < 2.4e-2 and rms < 5.0e-2 and psnr > 37.3, (q_rel, rms, d01, psnr)
 
 
 def test_sdxl_1024_full_width_bf16_graph_vs_oracle(dev, heavy_budget):
@@ -94,10 +94,10 @@ def test_sdxl_1024_full_width_bf16_graph_vs_oracle(dev, heavy_budget):
         print(f"\n[production SDXL{' fp8' if fp8 else ''}] bf16+graph batch {b} 1024x1024 vs oracle, {steps} steps, image 0: latents rms-rel {rms:.3e}; "
               f"image max|d| {d01:.4f} PSNR {psnr:.1f} dB")
         if not fp8:
-            # measured r2: rms 1.21e-2, PSNR 50.1 dB
+            # measured r2 (current synthetic weights): rms 9.6e-3, PSNR 52.5 dB
             assert rms < 2.5e-2 and psnr > 44.0, (rms, d01, psnr)
         else:
-            # measured r2: rms 1.49e-2, PSNR 48.7 dB
+            # measured r2 (current synthetic weights): rms 1.16e-2, PSNR 51.7 dB
             assert rms < 3e-2 and psnr > 42.7, (rms, d01, psnr)
         del pipe
         torch.cuda.empty_cache()

@@ -114,10 +114,11 @@ def test_bf16_graph_batch8_vs_oracle_short_trajectory(dev, prod):
     print(f"\n[production a] bf16+graph batch 8 vs oracle, {steps} steps, image 0: latents max-rel {lat_rel:.3e} rms-rel {lat_rms:.3e}; "
           f"image max|d| {d01:.4f} PSNR {psnr:.1f} dB, u8 max {du8.max()} mean {du8.mean():.3f}; "
           f"per-evaluation eps max-rel {max(eps_rel):.3e} rms-rel {max(eps_rms):.3e} ({['%.2e' % v for v in eps_rms]})")
-    # measured on MI355X (round 2): eps rms-rel 1.16e-2 at t=981, 7.2e-3..7.8e-3 after; max-rel 1.48e-2; latents rms-rel 2.19e-2
-    # (the CFG combine amplifies uncorrelated eps error by ~7.5*sqrt(2)); image PSNR 43.4 dB.  Bounds = 2x (PSNR - 6 dB).
-    assert max(eps_rms) < 2.4e-2 and max(eps_rel) < 3.0e-2, (eps_rel, eps_rms)
-    assert lat_rms < 4.4e-2 and psnr > 37.4, (lat_rel, lat_rms, d01, psnr)
+    # measured on MI355X (round 2, current synthetic weights): eps rms-rel 1.35e-2 at t=981, 8.3e-3..1.0e-2 after; max-rel
+    # 1.31e-2; latents rms-rel 2.66e-2 (the CFG combine amplifies uncorrelated eps error by ~7.5*sqrt(2)); image PSNR 41.4 dB.
+    # Bounds = 2x (PSNR - 6 dB).
+    assert max(eps_rms) < 2.7e-2 and max(eps_rel) < 3.0e-2, (eps_rel, eps_rms)
+    assert lat_rms < 5.4e-2 and psnr > 35.4, (lat_rel, lat_rms, d01, psnr)
 
 
 def test_bf16_vs_fp32_hip_batch8_50_steps(dev, prod, p32):
@@ -138,7 +139,8 @@ def test_bf16_vs_fp32_hip_batch8_50_steps(dev, prod, p32):
         lat_rms.append(((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item())
     print(f"\n[production b] bf16+graph batch 8 vs fp32 HIP, 50 steps: PSNR {['%.1f' % v for v in psnrs]} dB, max|d| "
           f"{['%.3f' % v for v in dmax]}, latents rms-rel {['%.2e' % v for v in lat_rms]}")
-    # measured (round 2): PSNR 43.8-45.2 dB, latents rms-rel 1.6e-2..1.9e-2.  Bounds = 2x the error (PSNR - 6 dB).
+    # measured (round 2): PSNR 44.2-44.6 dB (43.8-45.2 with the first weight set), latents rms-rel 1.7e-2..1.8e-2.
+    # Bounds = 2x the error (PSNR - 6 dB).
     assert min(psnrs) > 37.8 and max(lat_rms) < 4.0e-2, (psnrs, dmax, lat_rms)
 
 

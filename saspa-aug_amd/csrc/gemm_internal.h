@@ -10,6 +10,8 @@ __attribute__((visibility("hidden"))) int saspa_gemm_pp_launch(const SaspaGemmPa
 __attribute__((visibility("hidden"))) bool saspa_gemm_pp_eligible(const SaspaGemmParams& p);
 // split-K reduce + epilogue launch shared by both variants (saspa_gemm.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit);
+// N-partitioned tile order (weight-heavy problems): nbn / 8 if the launch should use it, else 0 (saspa_gemm.hip)
+__attribute__((visibility("hidden"))) int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles);
 // wave-specialised 8-wave kernel for short-K bf16 layers (saspa_gemm_ws.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s);
 __attribute__((visibility("hidden"))) bool saspa_gemm_ws_eligible(const SaspaGemmParams& p);

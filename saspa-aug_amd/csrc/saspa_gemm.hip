@@ -266,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
 // K-tiles are issued before the current tile's epilogue, so workgroups stream continuously
 // instead of loading / storing in lock-step bursts (short-K layers are memory-bound).
 template <typename T, int WM, int WN, bool PW>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, const int ntiles) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, const int ntiles, const int npart8) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -329,8 +329,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
   int ku = 0, cu = 0, dyu = 0, dxu = 0;       // FAST: wave-uniform k-state (tile start)
 
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
-    bm = t / nbn;
-    bn = t - bm * nbn;
+    if (npart8 > 0) {
+      // N-partitioned order (weight-heavy problems, host decides): the XCD of this block (L & 7 -> the x-th eighth of every
+      // round of G tiles) owns the x-th eighth of the N tiles for ALL row blocks, so its slice of the weights stays in
+      // its L2 while the activations stream through once per XCD
+      const int G8 = G >> 3;
+      const int k = t / G, r = t - k * G;
+      const int x = r / G8;
+      const int q = k * G8 + (r - x * G8);
+      bm = q / npart8;
+      bn = x * npart8 + (q - bm * npart8);
+    } else {
+      bm = t / nbn;
+      bn = t - bm * nbn;
+    }
     if (PW) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const SaspaGemmParams p, c
 // DMA of every 3x3 conv's K-tile (4 per K-tile on the 128-row tile), and this issue path does not forgive branches.
 template <typename T, int WM, int WN, int NWM, int NWN, bool PW, int NSTAGE, bool UP = false>
 __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 : 2) void gemm_dma_kernel(const SaspaGemmParams p,
-                                                                                                      const int ntiles_abl) {
+                                                                                                      const int ntiles_abl, const int npart8) {
   // diagnostic ablation (tools/gemm_ablate.py only; 0 in production): bits 28..30 of the tile count
   const int ntiles = ntiles_abl & 0x0fffffff;
 #ifdef SASPA_GEMM_ABLATION
@@ -608,8 +620,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
   int ku = 0, cu = 0, dyu = 0, dxu = 0;
 
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
-    bm = t / nbn;
-    bn = t - bm * nbn;
+    if (npart8 > 0) {
+      // N-partitioned order (weight-heavy problems, host decides): the XCD of this block (L & 7 -> the x-th eighth of every
+      // round of G tiles) owns the x-th eighth of the N tiles for ALL row blocks, so its slice of the weights stays in
+      // its L2 while the activations stream through once per XCD
+      const int G8 = G >> 3;
+      const int k = t / G, r = t - k * G;
+      const int x = r / G8;
+      const int q = k * G8 + (r - x * G8);
+      bm = q / npart8;
+      bn = x * npart8 + (q - bm * npart8);
+    } else {
+      bm = t / nbn;
+      bn = t - bm * nbn;
+    }
     if (PW) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
@@ -886,15 +910,16 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   static const bool dma_off = getenv("SASPA_GEMM_DMA") && atoi(getenv("SASPA_GEMM_DMA")) == 0;   // A/B knob
   static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;       // diagnostics only
   const int tiles_abl = tiles | (abl << 28);
+  const int npart8 = saspa_gemm_npart8(p, BM, BN, gx, tiles);
   const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
                     (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
   if (p.korder == SASPA_KORDER_CHUNK && !fast) return SASPA_ERANGE;   // only the DMA kernels walk K chunk-major
   if constexpr (NT != 256) {
     // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
     if (!fast) return SASPA_ERANGE;
-    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
-    else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3, true>), grid, dim3(NT), 0, s, p, tiles_abl);
-    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3>), grid, dim3(NT), 0, s, p, tiles_abl);
+    if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, true, 3>), grid, dim3(NT), 0, s, p, tiles_abl, npart8);
+    else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3, true>), grid, dim3(NT), 0, s, p, tiles_abl, npart8);
+    else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, NWM, NWN, false, 3>), grid, dim3(NT), 0, s, p, tiles_abl, npart8);
   } else if (fast) {
     // few tiles (<= ~1 workgroup per CU): spend the idle LDS on a 4-deep DMA ring (latency-bound
     // K loops); otherwise 2 stages and 2 workgroups per CU
@@ -902,17 +927,17 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
     constexpr bool can4 = (BM + BN) * 128 * 4 <= 160 * 1024;
     const bool deep = can4 && (force_st ? force_st == 4 : (long long)tiles * zy <= 320);
     if (deep) {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
-      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2, true>), grid, dim3(256), 0, s, p, tiles_abl);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
+      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2, true>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, can4 ? 4 : 2>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
     } else {
-      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles_abl);
-      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2, true>), grid, dim3(256), 0, s, p, tiles_abl);
-      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles_abl);
+      if (pw) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, true, 2>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
+      else if (p.upsample) hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2, true>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, WM, WN, 2, 2, false, 2>), grid, dim3(256), 0, s, p, tiles_abl, npart8);
     }
   } else {
-    if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles);
-    else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles);
+    if (pw) hipLaunchKernelGGL((gemm_kernel<T, WM, WN, true>), grid, dim3(256), 0, s, p, tiles, npart8);
+    else hipLaunchKernelGGL((gemm_kernel<T, WM, WN, false>), grid, dim3(256), 0, s, p, tiles, npart8);
   }
   SASPA_CHECK_LAUNCH();
   if (ksplit > 1) return saspa_gemm_splitk_reduce(p, s, ksplit);
@@ -1030,6 +1055,26 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
   if (ks > 8) ks = 8;
   if (ks > ktiles / 8) ks = ktiles / 8;
   return ks < 1 ? 1 : (int)ks;
+}
+
+// Tile order of a launch: 0 = M-partitioned (an XCD walks whole rows of N tiles: its activations stay in L2, the weights
+// stream through once per row block) or n = nbn / 8 > 0 = N-partitioned (an XCD owns an eighth of the N tiles for every row
+// block: its weight slice stays in L2, the activations stream through once per XCD).  Estimated beyond-L2 bytes decide;
+// profiles/r2_pmc_per_shape.txt has the measured ones (GEGLU projection at M = 16 384: 684 MB fetched for 28 MB of operands
+// with the M-partitioned order).  SASPA_GEMM_NPART=0 turns it off (A/B knob).
+int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles) {
+  static const bool off = getenv("SASPA_GEMM_NPART") && atoi(getenv("SASPA_GEMM_NPART")) == 0;
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  if (off || (long long)p.nb1 * p.nb2 != 1 || (nbn & 7) || (G & 7) || G <= 0 || tiles % G || p.N % BN) return 0;
+  const double esz = p.dtype == SASPA_BF16 ? 2.0 : 4.0;
+  const double a = (double)p.batch * p.hin * p.win * (p.c0 + p.c1) * esz;     // the input tensor (taps re-read from L2)
+  const double w = (double)p.N * p.K * esz;
+  static const double l2mb = getenv("SASPA_GEMM_NPART_L2MB") ? atof(getenv("SASPA_GEMM_NPART_L2MB")) : 3.8;   // of the 4 MiB per XCD
+  const double l2 = l2mb * (1 << 20);
+  const double g8 = G / 8.0;
+  const double mpart = a * (nbn > g8 ? nbn / g8 : 1.0) + w * (w <= l2 ? 8.0 : (double)nbm);
+  const double npart = 8.0 * a + w * (w / 8.0 <= l2 ? 1.0 : (double)nbm);
+  return npart < 0.75 * mpart ? nbn / 8 : 0;
 }
 
 int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int FN, bool PW, bool UP, bool ONEBAR>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, const int ntiles_abl) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, const int ntiles_abl, const int npart8) {
   // diagnostic ablation (tools/gemm_ablate.py, `make ABLATION=1` only): bits 28..31 of the tile count
   //   1: no MFMA   2: no fragment reads   4: no DMA issue   8: no barriers
   const int ntiles = ntiles_abl & 0x07ffffff;
@@ -129,8 +129,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   const int arow0 = wm * 128 + (wave & 3) * 8 + lr;    // A row of slice 0 handled by this lane; + 32 per slice
 
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
-    bm = t / nbn;
-    bn = t - bm * nbn;
+    if (npart8 > 0) {      // N-partitioned order (saspa_gemm.hip: saspa_gemm_npart8)
+      const int G8 = G >> 3;
+      const int k = t / G, r = t - k * G;
+      const int x = r / G8;
+      const int q = k * G8 + (r - x * G8);
+      bm = q / npart8;
+      bn = x * npart8 + (q - bm * npart8);
+    } else {
+      bm = t / nbn;
+      bn = t - bm * nbn;
+    }
     if (!PW) {
       int m = bm * BM + arow0;
       int b = m / hw;
@@ -569,9 +578,10 @@ int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;   // diagnostics only
   static const int stamp = getenv("SASPA_GEMM_STAMP") ? (atoi(getenv("SASPA_GEMM_STAMP")) & 1) : 0;
   const int ta = tiles | (abl << 28) | (stamp << 27);
-  if (pw) hipLaunchKernelGGL((gemm_pp_kernel<FN, true, false, ONEBAR>), grid, dim3(512), 0, s, p, ta);
-  else if (p.upsample) hipLaunchKernelGGL((gemm_pp_kernel<FN, false, true, ONEBAR>), grid, dim3(512), 0, s, p, ta);
-  else hipLaunchKernelGGL((gemm_pp_kernel<FN, false, false, ONEBAR>), grid, dim3(512), 0, s, p, ta);
+  const int npart8 = saspa_gemm_npart8(p, BM, BN, gx, tiles);
+  if (pw) hipLaunchKernelGGL((gemm_pp_kernel<FN, true, false, ONEBAR>), grid, dim3(512), 0, s, p, ta, npart8);
+  else if (p.upsample) hipLaunchKernelGGL((gemm_pp_kernel<FN, false, true, ONEBAR>), grid, dim3(512), 0, s, p, ta, npart8);
+  else hipLaunchKernelGGL((gemm_pp_kernel<FN, false, false, ONEBAR>), grid, dim3(512), 0, s, p, ta, npart8);
   SASPA_CHECK_LAUNCH();
   if (ksplit > 1) return saspa_gemm_splitk_reduce(p, s, ksplit);
   return 0;

@@ -71,7 +71,8 @@ def test_splitk_is_deterministic_and_matches(dev, variant, ks):
 
 @pytest.mark.parametrize("m,k,f,variant", [(4096, 320, 1280, 0), (300, 64, 128, 0), (1024, 128, 640, 0),
                                            (4096, 320, 1280, 2), (1000, 128, 640, 2),     # 8-wave 256x320 tiles (two packed groups per tile)
-                                           (4096, 1280, 5120, 0)])                          # AUTO picks the wide kernel
+                                           (4096, 1280, 5120, 0),                           # AUTO picks the wide kernel, N-partitioned tile order
+                                           (2048, 640, 2560, 0)])                           # 4-wave kernel, N-partitioned tile order
 def test_linear_fused_geglu(dev, m, k, f, variant):
     """GEGLU fused into the projection epilogue (value / gate rows regrouped per output tile)."""
     dtype = torch.bfloat16
@@ -126,6 +127,7 @@ CONV_CASES = [
     (2, 64, 64, 64, 640, 3, 1, False),   # 128x160 tiles, window path, 256 tiles
     (1, 16, 16, 512, 320, 3, 1, False),  # split-K conv (K = 4608)
     (2, 16, 16, 256, 640, 3, 1, True),   # split-K + upsample
+    (16, 8, 8, 1280, 1280, 3, 1, False), # deepest UNet level: split-K, N-partitioned tile order (weights >> activations)
 ]
 
 

@@ -1034,6 +1034,18 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
   const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
   const int ktiles = (p.K + bk - 1) / bk;
   static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);       // A/B knob
+  {
+    // exactly one wave of 128-row tiles on a pointwise layer: the wave-specialised kernel without K slices beats the 8-wave
+    // kernel on K slices (feed-forward output projection of the 16x16 level, (4096, 1280, 5120): 52 vs 76 us, and no slabs)
+    static const bool ws_on = !(getenv("SASPA_GEMM_WS") && atoi(getenv("SASPA_GEMM_WS")) == 0) &&
+                              !(getenv("SASPA_GEMM_WS_NOSPLIT") && atoi(getenv("SASPA_GEMM_WS_NOSPLIT")) == 0);   // A/B knobs
+    static const int ws_max = getenv("SASPA_GEMM_WS_MAXTILES") ? atoi(getenv("SASPA_GEMM_WS_MAXTILES")) : 512;
+    const int bn_t = (p.N % 160 == 0) ? 160 : 128;
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + bn_t - 1) / bn_t);
+    if (ws_on && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 && t128 >= 256 && t128 < ws_max &&
+        saspa_gemm_ws_eligible(p))
+      return 1;
+  }
   if (wide_ks && p.dtype == SASPA_BF16 && p.K >= 4096 && saspa_gemm_pp_eligible(p)) {
     const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
     if (fn) {

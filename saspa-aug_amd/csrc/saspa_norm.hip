@@ -44,7 +44,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const SaspaGroupNormPar
     else { src = reinterpret_cast<const T*>(p.x1); ld = p.ldx1; cc = ch - p.c0; }
     const int pbeg = split * pix_per_split;
     const int pend = min(p.hw, pbeg + pix_per_split);
-    for (int px = pbeg + py; px < pend; px += rows) {
+    // four pixels per trip: four independent 16-byte loads in flight per lane (the pass is latency / bandwidth bound)
+    int px = pbeg + py;
+    for (; px + 3 * rows < pend; px += 4 * rows) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* ptr = src + ((long long)b * p.hw + px + u * rows) * ld + cc;
+        if constexpr (sizeof(T) == 2) {
+          Elem<T>::load_chunk(ptr, v[u]);
+        } else {
+          Elem<T>::load_chunk(ptr, v[u]);
+          Elem<T>::load_chunk(ptr + 4, v[u] + 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += v[u][j]; ss[j] += v[u][j] * v[u][j]; }
+    }
+    for (; px < pend; px += rows) {
       const T* ptr = src + ((long long)b * p.hw + px) * ld + cc;
       float v[8];
       if constexpr (sizeof(T) == 2) {
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
   const int pbeg = blockIdx.x * ppb;
   const int pend = min(p.hw, pbeg + ppb);
   const bool silu = p.act == SASPA_ACT_SILU;
-  for (int px = pbeg + py; px < pend; px += rows) {
+  auto one = [&](const int px) __attribute__((always_inline)) {
     const long long pix = (long long)b * p.hw + px;
     const T* ptr = src + pix * ld + cc;
     float v[8];
@@ -176,7 +195,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
       Elem<T>::store_chunk(dst, v);
       Elem<T>::store_chunk(dst + 4, v + 4);
     }
+  };
+  // four pixels per trip: the compiler issues the four loads back to back before the first use
+  int px = pbeg + py;
+  for (; px + 3 * rows < pend; px += 4 * rows) {
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const T* ptr = src + ((long long)b * p.hw + px + u * rows) * ld + cc;
+      if constexpr (sizeof(T) == 2) {
+        Elem<T>::load_chunk(ptr, v[u]);
+      } else {
+        Elem<T>::load_chunk(ptr, v[u]);
+        Elem<T>::load_chunk(ptr + 4, v[u] + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = v[u][j] * scv[j] + shv[j];
+        if (silu) y = silu_f(y);
+        v[u][j] = y;
+      }
+      T* dst = reinterpret_cast<T*>(p.y) + ((long long)b * p.hw + px + u * rows) * p.ldy + ch;
+      if constexpr (sizeof(T) == 2) {
+        Elem<T>::store_chunk(dst, v[u]);
+      } else {
+        Elem<T>::store_chunk(dst, v[u]);
+        Elem<T>::store_chunk(dst + 4, v[u] + 4);
+      }
+    }
   }
+  for (; px < pend; px += rows) one(px);
 }
 
 // ---- LayerNorm: one wave per row, two-pass in registers ---------------------------------

@@ -2,6 +2,8 @@
 // HBM-bound: every access is a 16/32-byte vector per lane (8 channels).  GroupNorm is two launches: per-(image, pixel
 // split, channel slab, group) fp32 sums, then the apply pass, whose every workgroup first combines the (few KB of) sums
 // of ITS image in fp64 -- no finalize launch in between.  See include/saspa_hip.h.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -230,21 +232,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
   for (; px < pend; px += rows) one(px);
 }
 
-// ---- LayerNorm: one wave per row, two-pass in registers ---------------------------------
-template <typename T>
+// ---- LayerNorm: LPR lanes per row (64 / LPR rows per wave), NCH chunks of 8 channels per lane, two-pass in registers.
+// Narrow rows (320 / 640 channels = 40 / 80 chunks) take 16 / 32 lanes x 3 chunks, so a wave has 4 / 2 rows' loads in flight
+// and 83 % of its lanes busy instead of one row and 62 %.
+template <typename T, int LPR, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, int ldx, T* y, int ldy, long long rows, int C,
                                                         const float* gamma, const float* beta, float eps) {
-  constexpr int MAXCH = 4;  // C <= 2048
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int sub = lane % LPR;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < rows;
   const int C8 = C >> 3;
-  const T* xr = x + row * ldx;
-  float v[MAXCH][8];
+  const T* xr = x + (live ? row : 0) * ldx;
+  float v[NCH][8];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int chunk = lane + 64 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int chunk = sub + LPR * i;
     if (chunk < C8) {
       if constexpr (sizeof(T) == 2) {
         Elem<T>::load_chunk(xr + chunk * 8, v[i]);
@@ -259,22 +264,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, int ldx, T* 
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
+  auto row_sum = [](float a) __attribute__((always_inline)) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    return a;
+  };
+  const float mean = row_sum(sum) / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int chunk = lane + 64 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int chunk = sub + LPR * i;
     if (chunk < C8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
     }
   }
-  const float var = wave_sum(sq) / (float)C;
+  const float var = row_sum(sq) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
+  if (!live) return;
   T* yr = y + row * ldy;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int chunk = lane + 64 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int chunk = sub + LPR * i;
     if (chunk < C8) {
       float o[8];
 #pragma unroll
@@ -286,6 +297,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, int ldx, T* 
         Elem<T>::store_chunk(yr + chunk * 8 + 4, o + 4);
       }
     }
+  }
+}
+
+template <typename T>
+void launch_layernorm(hipStream_t s, const T* x, int ldx, T* y, int ldy, long long rows, int C, const float* gamma, const float* beta,
+                      float eps) {
+  const int C8 = C >> 3;
+  static const bool narrow = !(getenv("SASPA_LN_NARROW") && atoi(getenv("SASPA_LN_NARROW")) == 0);   // A/B knob
+  if (narrow && C8 <= 48) {
+    hipLaunchKernelGGL((layernorm_kernel<T, 16, 3>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps);
+  } else if (narrow && C8 <= 96) {
+    hipLaunchKernelGGL((layernorm_kernel<T, 32, 3>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps);
+  } else {
+    hipLaunchKernelGGL((layernorm_kernel<T, 64, 4>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps);
   }
 }
 
@@ -348,11 +373,10 @@ extern "C" int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int l
   if (C % 8 || ldx % 8 || ldy % 8 || !aligned16(x) || !aligned16(y)) return SASPA_EALIGN;
   if (C > 2048) return SASPA_ERANGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const unsigned grid = (unsigned)((rows + 3) / 4);
   if (dtype == SASPA_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, C, gamma, beta, eps);
+    launch_layernorm<bf16_t>(s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, C, gamma, beta, eps);
   else if (dtype == SASPA_F32)
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, rows, C, gamma, beta, eps);
+    launch_layernorm<float>(s, (const float*)x, ldx, (float*)y, ldy, rows, C, gamma, beta, eps);
   else
     return SASPA_EINVAL;
   SASPA_CHECK_LAUNCH();

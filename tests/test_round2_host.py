@@ -93,3 +93,56 @@ def test_clip_bpe_matches_transformers_on_a_synthetic_vocabulary(tmp_path):
         want = ref(ptxt, padding="max_length", max_length=77, truncation=True)["input_ids"]
         got = ours(ptxt)[0].tolist()
         assert got == want, (ptxt, got[:20], want[:20])
+
+
+def test_fp8_weight_quantisation_round_trip():
+    """weights.quantize_fp8: per-output-channel scale = row amax / 448, OCP e4m3 bytes; dequantised within half an ulp of
+    3 mantissa bits; zero rows keep scale 1."""
+    import torch
+    from saspa_aug_amd import weights as W
+    w = torch.randn(64, 256, generator=torch.Generator().manual_seed(0)) * torch.logspace(-3, 1, 64)[:, None]
+    w[5] = 0
+    q, s = W.quantize_fp8(w)
+    assert q.dtype == torch.uint8 and q.shape == w.shape and s.shape == (64,)
+    assert torch.allclose(s[torch.arange(64) != 5], w.abs().amax(1)[torch.arange(64) != 5] / 448.0) and s[5] == 1.0
+    d = W.dequantize_fp8(q, s)
+    assert ((d - w).abs() <= 0.0625 * w.abs() + s[:, None] * 2 ** -9 + 1e-12).all()
+    assert (d[5] == 0).all() and (q.view(torch.float8_e4m3fn).float().abs().amax(1)[torch.arange(64) != 5] == 448).all()
+
+
+def test_pack_geglu_tile_layout():
+    import torch
+    from saspa_aug_amd import weights as W
+    f, k = 192, 8
+    w = torch.arange(2 * f * k, dtype=torch.float32).view(2 * f, k)
+    b = torch.arange(2 * f, dtype=torch.float32)
+    wp, bp = W.pack_geglu_tile(w, b, 128)
+    # tile t = [values of features 64t .. 64t+63 | their gates]
+    for t in range(3):
+        assert torch.equal(bp[128 * t:128 * t + 64], b[64 * t:64 * t + 64])
+        assert torch.equal(bp[128 * t + 64:128 * (t + 1)], b[f + 64 * t:f + 64 * t + 64])
+    assert torch.equal(wp[64], w[f]) and W.pack_geglu_tile(w[:200], b[:200], 128) is None
+    assert all(torch.equal(a, c) for a, c in zip(W.pack_geglu(w[:320], b[:320]), W.pack_geglu_tile(w[:320], b[:320], 160)))
+
+
+def test_large_tensor_synthesis_is_deterministic_and_leaves_golden_kinds_alone():
+    """weights._fill_big: tensors >= 1 Mi elements are drawn chunk-wise on a thread pool (per-chunk seeds), reproducibly; the
+    kinds behind reference goldens (cal, clip_rn50, hed) stay on the sequential generator."""
+    import torch
+    from saspa_aug_amd import config as CFG
+    from saspa_aug_amd import weights as W
+    cfg = dict(CFG.SD15["text"])
+    a, b = W.synth_state_dict("text", cfg, 3), W.synth_state_dict("text", cfg, 3)
+    big = "text_model.embeddings.token_embedding.weight"
+    assert a[big].numel() >= W._BIG and all(torch.equal(a[k], b[k]) for k in a)
+    c = W.synth_state_dict("text", cfg, 4)
+    assert not torch.equal(a[big], c[big])
+    assert abs(float(a[big].std()) - 0.5) < 5e-3 and abs(float(a[big].mean())) < 1e-3
+    # an exempt kind: identical to drawing everything from ONE sequential generator
+    g = torch.Generator().manual_seed(21)
+    hed = W.synth_state_dict("hed", CFG.HED, 21)
+    first = 110.0 + 20.0 * torch.rand((1, 3, 1, 1), generator=g)
+    assert torch.equal(hed["norm"], first)
+    w0 = torch.randn((64, 3, 3, 3), generator=g) * (1.0 / (27 ** 0.5))
+    assert torch.equal(hed["block1.convs.0.weight"], w0)
+    assert hed["block5.convs.2.weight"].numel() >= W._BIG          # large, and still sequential

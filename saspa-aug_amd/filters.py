@@ -16,7 +16,6 @@ are processed in batches.  Both models run on the exact-fp32 MFMA path by defaul
 
 No CPU or eager-PyTorch arithmetic: torch is used for device memory and layout copies (cat / transpose) only."""
 import logging
-import math
 import os
 from pathlib import Path
 

@@ -7,7 +7,6 @@ Mirrors what the reference's pipelines do on the CPU through `CLIPImageProcessor
 SURVEY 8a a7.9) and `BlipImageProcessor` (resize to 224 x 224 bicubic; a8).  The coefficient tables depend only on the
 sizes: they are computed once per (in, out, crop) on the host in double precision exactly as Pillow's
 `precompute_coeffs` / `normalize_coeffs_8bpc` do and cached on the device; all pixel arithmetic runs in the kernels."""
-import ctypes as C
 import math
 from functools import lru_cache
 

@@ -138,7 +138,12 @@ typedef struct SaspaAttnParams {
   int nq, nk;
   float scale;
   int causal;
+  int flags;                               /* SASPA_ATTN_* bits (ABI 11) */
 } SaspaAttnParams;
+/* The queries already carry scale * log2(e) (folded into the to_q weights when they are packed): K Q^T is the
+ * log2-domain logit, `scale` is ignored, and the kernel runs the loop with no per-score multiply / subtract / max
+ * (saspa_attn.hip, "v2").  Same result up to the rounding point of the scale. */
+#define SASPA_ATTN_QPRESCALED 1
 int saspa_flash_attn_bf16(const SaspaAttnParams* p, void* stream);
 
 /* row softmax in place over a [rows][ld] matrix (unfused attention path: fp32

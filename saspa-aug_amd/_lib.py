@@ -33,7 +33,7 @@ class AttnParams(C.Structure):
         ("vt", C.c_void_p), ("ldvt", C.c_int), ("svb", C.c_longlong),
         ("o", C.c_void_p), ("ldo", C.c_int), ("sob", C.c_longlong),
         ("batch", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("nq", C.c_int), ("nk", C.c_int),
-        ("scale", C.c_float), ("causal", C.c_int),
+        ("scale", C.c_float), ("causal", C.c_int), ("flags", C.c_int),
     ]
 
 

@@ -15,6 +15,8 @@
 // LDS images: K tile rows padded to an odd number of 16-byte slots (conflict-free
 // ds_read_b128 across 32 distinct rows); V^T rows = 64 keys + 8 bytes pad (conflict-free
 // ds_read_b64: row stride 136 B = 8*17).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -268,13 +270,320 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   }
 }
 
+// ---- v2: the loop for PRESCALED queries (SaspaAttnParams.flags & SASPA_ATTN_QPRESCALED) -------------------------
+// The caller has folded scale * log2(e) into the query projection's weights, so K Q^T already is the log2-domain
+// logit.  That removes the two VALU instructions per score the loop above spends besides the exponential:
+//   * the running reference level m rides the QK^T MFMA as its C operand (a 16-register splat of -m that only
+//     changes when m does): the accumulator comes out as s - m, and p = exp2(acc) needs no subtract / FMA;
+//   * softmax is exact for ANY reference level (it cancels in O / l), it only has to keep exp2 in range.  So m is
+//     not the running maximum but "the maximum seen at the last update + BIAS": p stays <= 2^-BIAS until a logit
+//     exceeds that maximum by BIAS + 1, which the loop detects without a max chain -- p >= 2 <=> bit 14 of its
+//     bf16 pattern, so OR-ing the packed P registers (v_or3_b32, 16 per 128-key tile) and testing 0x40004000
+//     is an exact "some p >= 2.0" (inf / NaN included).  Only then (and on tile 0, which sets the level) the
+//     slow path takes the true row maximum, moves m, rescales O once and re-exponentiates the tile.
+//     bf16 / fp32 keep 8 exponent bits, so p ~ 2^-8 loses no relative precision; l and O are fp32.
+//   * V^T tile keys are stored permuted inside each 16-key group ([0-3 | 8-11 | 4-7 | 12-15]) so that the A
+//     operand of the PV MFMA (k order 8*(j>>2) + 4*(lane>>5) + (j&3)) is ONE ds_read_b128 per lane instead of
+//     a ds_read2_b64; rows are KT*2 + 16 bytes (an odd number of 16-byte slots: conflict-free).
+//   * DB: two LDS tile buffers, one barrier per tile (tile t+1 is written while tile t is multiplied).
+template <int KS, int NB, bool ONES, int KT, bool DB>
+__global__ __launch_bounds__(256) void flash_attn_v2_kernel(const SaspaAttnParams p) {
+  constexpr int NKB = KT / 32;
+  constexpr int VCH = KT / 8;
+  constexpr int KSLOTS = (2 * KS) | 1;
+  constexpr int KCH = 2 * KS;
+  constexpr int DV = NB * 32;
+  constexpr int VROW = KT * 2 + 16;
+  constexpr int K_BYTES = KT * KSLOTS * 16;
+  constexpr int V_BYTES = DV * VROW;
+  constexpr int BUF = K_BYTES + V_BYTES;
+  constexpr int NCH_K = (KT * KCH + 255) / 256;
+  constexpr int NCH_V = (DV * VCH + 255) / 256;
+  constexpr float BIAS = 8.0f;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int grp = lin / (8 * gx), rr = lin - grp * 8 * gx;
+  const int gsz = min(8, nbh - grp * 8);
+  const int bh = grp * 8 + rr % gsz, xq = rr / gsz;
+  const int head = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
+  const int D = p.D, D8 = D >> 3;
+  const int q0 = xq * 128 + wave * 32;
+  const int qi = q0 + r;
+
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int d = 16 * s + 8 * h;
+    qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kp), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned kInv = 0x80000000u;
+  unsigned koff[NCH_K], voff[NCH_V];
+  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_kc[NCH_V];
+#pragma unroll
+  for (int i = 0; i < NCH_K; ++i) {
+    const int q = tid + 256 * i;
+    const int key = q / KCH, ch = q - key * KCH;
+    k_key[i] = key;
+    k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
+    koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH_V; ++i) {
+    const int q = tid + 256 * i;
+    const int d = q / VCH, kc = q - d * VCH;
+    v_kc[i] = kc;
+    // chunk kc = keys 8kc .. 8kc+7 of 16-key group kc >> 1: its two 4-key pieces go to 8-byte slots (kc & 1) and 2 + (kc & 1)
+    v_lds[i] = (q < DV * VCH && d < D) ? d * VROW + (kc >> 1) * 32 + (kc & 1) * 8 : -1;
+    voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
+  }
+  // rows D .. DV-1 of the V^T tile never change: ones (denominator row, when ONES) / zeros -- in every buffer
+  for (int q = tid; q < DV * VCH; q += 256) {
+    const int d = q / VCH, kc = q - d * VCH;
+    if (d >= D) {
+      const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
+#pragma unroll
+      for (int bf = 0; bf < (DB ? 2 : 1); ++bf)
+        *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + d * VROW + kc * 16) = u32x4{fill, fill, fill, fill};
+    }
+  }
+  u32x4 kreg[NCH_K], vreg[NCH_V];
+
+  auto load_tile = [&](int key0) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i) {
+      unsigned o = koff[i];
+      if (tail && key0 + k_key[i] >= p.nk) o = kInv;
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)o, (int)sk, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      unsigned o = voff[i];
+      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+    }
+  };
+  auto store_tile = [&](int key0, unsigned char* buf) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    unsigned char* ksm = buf;
+    unsigned char* vsm = buf + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i)
+      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      if (v_lds[i] >= 0) {
+        u32x4 v = vreg[i];
+        if (tail) {
+          const int nvalid = p.nk - (key0 + v_kc[i] * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
+            v[e] &= keep;
+          }
+        }
+        u32x2* dst = reinterpret_cast<u32x2*>(vsm + v_lds[i]);
+        dst[0] = u32x2{v.x, v.y};
+        dst[2] = u32x2{v.z, v.w};
+      }
+    }
+  };
+
+  f32x16 acc_o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
+  f32x16 negm;                                      // -m (reference level of this lane's query), splat
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  float l_run = 0.f;                                // VALU row-sum (only when !ONES)
+
+  const int ntiles = (p.nk + KT - 1) / KT;
+  load_tile(0);
+  if (DB) {
+    store_tile(0, smem);
+    if (ntiles > 1) load_tile(KT);
+    __syncthreads();
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * KT;
+    const unsigned char* buf;
+    if (DB) {
+      buf = smem + (t & 1) * BUF;
+      if (t + 1 < ntiles) {
+        store_tile(key0 + KT, smem + ((t + 1) & 1) * BUF);   // read last in iteration t-1: every wave has passed its barrier
+        if (t + 2 < ntiles) load_tile(key0 + 2 * KT);
+      }
+    } else {
+      buf = smem;
+      __syncthreads();
+      store_tile(key0, smem);
+      __syncthreads();
+      if (t + 1 < ntiles) load_tile(key0 + KT);
+    }
+    const unsigned char* ksm = buf;
+    const unsigned char* vsm = buf + K_BYTES;
+
+    // ---- S'^T = K Q^T - m: the reference level is the MFMA's C operand ----
+    f32x16 acc_s[NKB];
+    u32x4 kf[2][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf[0][s] = *reinterpret_cast<const u32x4*>(ksm + (r * KSLOTS + 2 * s + h) * 16);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          kf[(kb + 1) & 1][s] = *reinterpret_cast<const u32x4*>(ksm + (((kb + 1) * 32 + r) * KSLOTS + 2 * s + h) * 16);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb & 1][s]), __builtin_bit_cast(bf16x8, qf[s]),
+                                                            s == 0 ? negm : acc_s[kb], 0, 0, 0);
+    }
+    if (key0 + KT > p.nk || p.causal) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= p.nk || (p.causal && key > qi)) acc_s[kb][i] = -INFINITY;
+        }
+    }
+    // ---- P = exp2(S'), packed; OR of the bf16 patterns tells whether any p reached 2.0 ----
+    unsigned pk[NKB][8];
+    unsigned orv = 0u;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(acc_s[kb][2 * j]), p1 = __builtin_amdgcn_exp2f(acc_s[kb][2 * j + 1]);
+        if (!ONES) psum += p0 + p1;
+        pk[kb][j] = pack2(p0, p1);
+        orv |= pk[kb][j];
+      }
+    if (__any(t == 0 || (orv & 0x40004000u) != 0u)) {
+      // slow path (wave-uniform): true row maximum of this tile relative to the current level
+      float mx = acc_s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc_s[kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float delta = t == 0 ? mx + BIAS : fmaxf(mx + BIAS, 0.f);   // the level only ever rises after tile 0
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] += -delta;
+      if (t != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        if (!ONES) l_run *= alpha;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
+      }
+      psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(acc_s[kb][2 * j] - delta), p1 = __builtin_amdgcn_exp2f(acc_s[kb][2 * j + 1] - delta);
+          if (!ONES) psum += p0 + p1;
+          pk[kb][j] = pack2(p0, p1);
+        }
+    }
+    if (!ONES) l_run += psum;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int ks = 0; ks < 2 * NKB; ++ks) {
+      const int kb = ks >> 1, half = ks & 1;
+      const u32x4 pf = {pk[kb][4 * half + 0], pk[kb][4 * half + 1], pk[kb][4 * half + 2], pk[kb][4 * half + 3]};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4 vf = *reinterpret_cast<const u32x4*>(vsm + (nb * 32 + r) * VROW + ks * 32 + 16 * h);
+        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+      }
+    }
+    if (DB) __syncthreads();      // tile t consumed by everyone; tile t+1 visible to everyone
+  }
+
+  float l_tot;
+  if (ONES) {
+    float lsel = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * nb + 8 * g == D) lsel = acc_o[nb][4 * g];
+    l_tot = __shfl(lsel, r, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
+  const float inv = 1.0f / l_tot;
+  if (qi < p.nq) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * nb + 8 * g + 4 * h;
+        if (d < D) {
+          float v[4] = {acc_o[nb][4 * g + 0] * inv, acc_o[nb][4 * g + 1] * inv, acc_o[nb][4 * g + 2] * inv,
+                        acc_o[nb][4 * g + 3] * inv};
+          Elem<bf16_t>::store4(O + (long long)qi * p.ldo + d, v);
+        }
+      }
+  }
+}
+
 template <int KS, int NB>
-int launch_attn(const SaspaAttnParams& p, hipStream_t s) {
+int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
+  SaspaAttnParams p = p0;
   dim3 grid((p.nq + 127) / 128, p.heads, p.batch);
   // 128-key tiles for the long self-attention sequences at head dims <= 96 (register budget);
   // 64-key tiles otherwise (cross-attention has 77 keys, d = 160 needs the registers for O^T)
   constexpr bool BIG_OK = KS <= 6;
   const bool big = BIG_OK && p.nk >= 512;
+  // A/B knobs (diagnostics): SASPA_ATTN_MODE=0 runs prescaled queries through the v1 loop (c = 1), =1 v2 with one
+  // LDS buffer, =2 v2 with two buffers / one barrier per tile
+  const char* me = getenv("SASPA_ATTN_MODE");   // read per launch: tools/attn_bench.py flips it inside one process
+  const int mode = me ? atoi(me) : 2;
+  if (p.flags & SASPA_ATTN_QPRESCALED) {
+    // v2 keeps S' and the packed P live together: 128-key tiles fit the 256-register budget (two waves per SIMD) up
+    // to d = 48, 64-key tiles up to d = 96; wider heads (SD-1.5's 16x16 / 8x8 levels, d = 160) run the v1 loop
+    constexpr bool V2_OK = KS <= 6;
+    // short key sequences (cross-attention: 77 keys = two tiles, the first of which always takes the slow path) are
+    // faster on the v1 loop (tools/attn_bench.py: 40 vs 44 us at level 0)
+    if (mode == 0 || !V2_OK || !big) {
+      p.scale = 0.6931471805599453f;       // the v1 loop multiplies by log2(e): net factor 1
+    } else if constexpr (V2_OK) {
+      constexpr int KTB = KS <= 3 ? 128 : 64;
+#define SASPA_V2(ONES_, DB_) hipLaunchKernelGGL((flash_attn_v2_kernel<KS, NB, ONES_, KTB, DB_>), grid, dim3(256), 0, s, p)
+      const bool db = mode >= 2;
+      if (p.D < 32 * NB) { if (db) SASPA_V2(true, true); else SASPA_V2(true, false); }
+      else { if (db) SASPA_V2(false, true); else SASPA_V2(false, false); }
+#undef SASPA_V2
+      SASPA_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (p.D < 32 * NB) {
     if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64>), grid, dim3(256), 0, s, p);

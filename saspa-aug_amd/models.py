@@ -69,10 +69,17 @@ class _Packed:
         self.p[name + ".g"] = _f32(self.sd[name + ".weight"], self.dev)
         self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
 
-    def attn(self, name, self_attn, has_bias=False):
+    def attn(self, name, self_attn, has_bias=False, qscale=None):
         """Fused [to_q; to_k] for self-attention, to_v kept separate (consumed as the A
-        operand of the transposed projection); v bias folded into the out bias."""
+        operand of the transposed projection); v bias folded into the out bias.
+        qscale: fold this factor (head_dim^-0.5 * log2 e) into the to_q rows BEFORE the cast to the storage dtype,
+        so that K Q^T is the log2-domain logit the flash kernel's prescaled loop expects (SASPA_ATTN_QPRESCALED);
+        one rounding either way: bf16(c * w) here, bf16(w) and a multiply per score otherwise."""
         sd = self.sd
+        if qscale is not None:
+            assert not has_bias
+            sd = dict(sd)
+            sd[name + ".to_q.weight"] = sd[name + ".to_q.weight"].to(torch.float32) * float(qscale)
         if self_attn:
             wq, wk = sd[name + ".to_q.weight"], sd[name + ".to_k.weight"]
             self.p[name + ".qk.w"] = torch.cat([wq, wk], 0).contiguous().to(self.dev, self.dtype)
@@ -104,17 +111,23 @@ def project_vt(x, wv, nk):
     return vt
 
 
-def attention_core(q, k, vt, heads, nq, nk, causal=False):
+ATTN_LOG2E = 1.4426950408889634
+
+
+def attention_core(q, k, vt, heads, nq, nk, causal=False, prescaled=False):
     """q: [B,nq,C] view, k: [B,nk,C] view, vt: [B,C,ld].  bf16 with head dim <= 160: fused
     flash kernel; otherwise (fp32 parity mode, 512-wide VAE head): scores GEMM -> row softmax
-    -> PV GEMM, all batched over (batch, head)."""
+    -> PV GEMM, all batched over (batch, head).
+    prescaled: q was projected with head_dim^-0.5 * log2(e) folded into its weights (_Packed.attn(qscale=...));
+    only the flash path takes such queries."""
     b = q.shape[0]
     c = vt.shape[1]
     d = c // heads
     out = torch.empty((b, nq, c), device=q.device, dtype=q.dtype)
     scale = d ** -0.5
     if q.dtype == torch.bfloat16 and d <= 160:
-        return ops.flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal)
+        return ops.flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal, prescaled=prescaled)
+    assert not prescaled, "prescaled queries exist for the flash path only"
     lds = ops.round8(nk)
     assert vt.stride(1) >= lds
     scores = torch.empty((b, heads, nq, lds), device=q.device, dtype=q.dtype)
@@ -168,8 +181,13 @@ class _Net:
             t = f"{pfx}.transformer_blocks.{d}"
             for n in ("norm1", "norm2", "norm3"):
                 pk.norm(f"{t}.{n}")
-            pk.attn(t + ".attn1", True)
-            pk.attn(t + ".attn2", False)
+            # bf16 networks with flash-sized heads: softmax scale * log2(e) folded into the to_q rows
+            c = pk.sd[t + ".norm1.weight"].numel()
+            qs = (c // heads) ** -0.5 * ATTN_LOG2E if (self.dtype == torch.bfloat16 and c // heads <= 160) else None
+            pk.attn(t + ".attn1", True, qscale=qs)
+            pk.attn(t + ".attn2", False, qscale=qs)
+            if qs is not None:
+                self.qscaled[t] = qs
             packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
                 if self.dtype == torch.bfloat16 else None
             if packed is not None:          # bf16: GEGLU fused into the projection's epilogue
@@ -187,7 +205,7 @@ class _Net:
 
     def _pack_encoder(self):
         cfg, pk = self.cfg, self.pk
-        self.resnets_with_temb, self.blocks, self.tr_info, self.fused_geglu = [], [], {}, set()
+        self.resnets_with_temb, self.blocks, self.tr_info, self.fused_geglu, self.qscaled = [], [], {}, set(), {}
         pk.conv("conv_in")
         pk.linear("time_embedding.linear_1", torch.float32)
         pk.linear("time_embedding.linear_2", torch.float32)
@@ -297,7 +315,7 @@ class _Net:
         """e4m3 copies (per-output-channel scales) of the two projections that read a LayerNorm's output; the GEGLU
         projection's rows are regrouped for the fp8 kernel's 128-column tiles."""
         sd, p = self.pk.sd, self.p
-        wq, sw = W.quantize_fp8(sd[t + ".attn2.to_q.weight"])
+        wq, sw = W.quantize_fp8(sd[t + ".attn2.to_q.weight"].float() * self.qscaled.get(t, 1.0))   # same fold as the bf16 rows
         p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"] = wq.to(self.dev), sw.to(self.dev)
         wg, bg = W.pack_geglu_tile(sd[t + ".ff.net.0.proj.weight"].float(), sd[t + ".ff.net.0.proj.bias"].float(), 128)
         wq, sw = W.quantize_fp8(wg)
@@ -318,14 +336,15 @@ class _Net:
             n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
             qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
             vt = project_vt(n1, p[t + ".attn1.v.w"], n)
-            o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n)
+            pre = t in self.qscaled
+            o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
             h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
             if t in self.fp8_blocks:
                 # W8A8: LayerNorm + per-token quantisation in one pass, e4m3 x e4m3 MFMA, scales applied in the epilogue
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
                 q = ops.linear_fp8(q8, s8, p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"])
                 k, vtc, nk = self.ctx_kv[t]
-                o = attention_core(q, k, vtc, heads, n, nk)
+                o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
                 ff = ops.linear_fp8(q8, s8, p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"],
@@ -336,7 +355,7 @@ class _Net:
             n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
             q = ops.linear(n2, p[t + ".attn2.q.w"])
             k, vtc, nk = self.ctx_kv[t]
-            o = attention_core(q, k, vtc, heads, n, nk)
+            o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
             h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
             n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])

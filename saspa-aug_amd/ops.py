@@ -258,9 +258,10 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     return out
 
 
-def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False):
+def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False, prescaled=False):
     """q: [B, nq, >=heads*d] view, k: [B, nk, >=heads*d] view, vt: [B, heads*d, ldvt] (keys
-    contiguous), out: [B, nq, >=heads*d] view.  bf16 only."""
+    contiguous), out: [B, nq, >=heads*d] view.  bf16 only.  prescaled: q already carries scale * log2(e)
+    (folded into the to_q weights, weights.ATTN_LOG2E) -> SASPA_ATTN_QPRESCALED, `scale` is ignored."""
     _check_dev(q, k, vt, out)
     lib = _lib.load()
     if q.dtype != torch.bfloat16:
@@ -271,7 +272,7 @@ def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False):
     p.vt, p.ldvt, p.svb = _ptr(vt), vt.stride(1), vt.stride(0)
     p.o, p.ldo, p.sob = _ptr(out), out.stride(1), out.stride(0)
     p.batch, p.heads, p.D, p.nq, p.nk = q.shape[0], heads, d, nq, nk
-    p.scale, p.causal = float(scale), int(causal)
+    p.scale, p.causal, p.flags = float(scale), int(causal), (1 if prescaled else 0)
     _launch("flash_attn", 4.0 * q.shape[0] * heads * nq * nk * d,
             lambda: _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16"),
             (q.shape[0], heads, nq, nk, d))

@@ -260,6 +260,59 @@ def test_flash_attn_rescale_branch(dev):
     assert_close(out.float().cpu(), ref, dtype, what="flash rescale")
 
 
+def _prescaled_q(qq, d):
+    """What the folded to_q weights produce: bf16(q * d^-0.5 * log2 e); the reference uses the SAME rounded queries."""
+    qs = q(qq * (d ** -0.5 * 1.4426950408889634), torch.bfloat16)
+    return qs, qs / (d ** -0.5 * 1.4426950408889634)
+
+
+@pytest.mark.parametrize("d,heads,nq,nk,causal", [
+    (40, 8, 200, 200, False), (80, 4, 300, 300, False), (160, 2, 256, 256, False), (64, 3, 77, 77, True),
+    (40, 8, 130, 77, False), (8, 4, 64, 64, False), (16, 2, 33, 200, False), (32, 4, 128, 64, False),
+    (40, 2, 1024, 1024, False), (64, 2, 640, 1024, False), (48, 1, 100, 513, False)])
+def test_flash_attn_prescaled(dev, d, heads, nq, nk, causal):
+    """SASPA_ATTN_QPRESCALED (v2 loop: reference level on the MFMA C operand, OR-bit overflow check)."""
+    dtype = torch.bfloat16
+    bsz, c = 2, heads * d
+    qs, qeff = _prescaled_q(_rand(bsz, nq, c, seed=21), d)
+    kk = q(_rand(bsz, nk, c, seed=22), dtype)
+    vv = q(_rand(bsz, nk, c, seed=23), dtype)
+    ref = _ref_attn(qeff, kk, vv, heads, causal)
+    ldvt = ops.round8(nk) + 8
+    vt = torch.full((bsz, c, ldvt), float("nan"), device=dev, dtype=dtype)
+    vt[:, :, :nk] = vv.transpose(1, 2).to(dev, dtype)
+    qkbuf = torch.zeros(bsz, max(nq, nk), 2 * c, device=dev, dtype=dtype)
+    qkbuf[:, :nq, :c] = qs.to(dev, dtype)
+    qkbuf[:, :nk, c:] = kk.to(dev, dtype)
+    out = torch.zeros(bsz, nq, c, device=dev, dtype=dtype)
+    ops.flash_attn(qkbuf[:, :nq, :c], qkbuf[:, :nk, c:], vt, out, heads, d, nq, nk, 123.0, causal, prescaled=True)   # scale ignored
+    assert_close(out.float().cpu(), ref, dtype, what=f"flash prescaled d={d} nq={nq} nk={nk}")
+
+
+@pytest.mark.parametrize("spike,shift", [(6.0, 0.0), (60.0, 0.0), (1.0, -40.0), (6.0, 25.0)])
+def test_flash_attn_prescaled_level_moves(dev, spike, shift):
+    """The v2 loop only moves its reference level when some p reaches 2.0: force that at a late KV tile (spiked key), with
+    logits far below / above zero (shift: every key gets a component along every query's common direction), and a spike
+    large enough that exp2 of the stale level overflows to inf (60 x)."""
+    dtype = torch.bfloat16
+    bsz, heads, d, n = 1, 1, 40, 512
+    qq = _rand(bsz, n, d, seed=24)
+    kk = _rand(bsz, n, d, seed=25)
+    vv = q(_rand(bsz, n, d, seed=26), dtype)
+    qq[..., 0] = 1.0                                 # common direction: k[..., 0] shifts every logit of every query
+    kk[..., 0] = shift
+    kk[0, 300] = qq[0, 5] * spike                    # query 5 meets a huge score in the 3rd 128-key tile
+    kk[0, 450] = qq[0, 77] * spike * 1.5             # and query 77 in the 4th
+    qs, qeff = _prescaled_q(qq, d)
+    kk = q(kk, dtype)
+    ref = _ref_attn(qeff, kk, vv, heads)
+    vt = vv.transpose(1, 2).contiguous().to(dev, dtype)
+    out = torch.zeros(bsz, n, d, device=dev, dtype=dtype)
+    ops.flash_attn(qs.to(dev, dtype), kk.to(dev, dtype), vt, out, heads, d, n, n, 1.0, prescaled=True)
+    assert torch.isfinite(out).all()
+    assert_close(out.float().cpu(), ref, dtype, what=f"flash prescaled level move spike={spike} shift={shift}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("causal", [False, True])
 def test_softmax_rows(dev, dtype, causal):

@@ -16,6 +16,7 @@
 // ds_read_b128 across 32 distinct rows); V^T rows = 64 keys + 8 bytes pad (conflict-free
 // ds_read_b64: row stride 136 B = 8*17).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -553,6 +554,361 @@ __global__ __launch_bounds__(256) void flash_attn_v2_kernel(const SaspaAttnParam
   }
 }
 
+// ---- v3: v2's arithmetic, software-pipelined inside the wave ------------------------------------------------------
+// v2 runs QK^T (matrix pipe only), the exponentials (VALU only) and PV (matrix pipe only) one after the other and
+// leaves the overlap to whichever other wave shares the SIMD; measured, the two waves of a SIMD overlap poorly
+// (46 % MFMA busy with 40 % of the VALU work removed).  Here ONE wave carries two independent instruction streams
+// through every 64-key tile step t:
+//     matrix pipe:  O += V(t-1) P(t-1)        and        S(t+1) = K(t+1) Q - m
+//     VALU:         P(t) = exp2(S(t)), packed, OR-checked
+// (S and P ping-pong between two register sets, the loop is unrolled by two so every index is static), dealt by
+// hand into one MFMA | LDS read | a few VALU issue pattern and pinned with sched_barrier.  If the check moves the
+// reference level (rare), S(t+1) -- computed against the old level -- takes the same delta.  K / V^T tiles live in a
+// 4-slot LDS ring written two steps ahead (global -> registers one step earlier still): one barrier per tile, no tile
+// is overwritten before the step after its last read.  64-key tiles keep the whole wave below 256 registers, so
+// two workgroups still share a CU.
+// ABL (diagnostics, `make ABLATION=1` + SASPA_ATTN_ABLATE only; 0 in the shipped library): 1 no exponentials, 2 no MFMAs,
+// 4 no LDS fragment reads, 8 no staging (global loads / LDS stores / barriers), 16 stamps (s_memtime / s_memrealtime of
+// the tile loop of every workgroup's thread 0 behind the output tensor: tools/attn_ablate.py)
+template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAttnParams p) {
+  // NW waves of 32 queries per workgroup: 8 waves halve the K / V^T bytes every query block pulls through L1 / LDS
+  // (the staging is the largest single cost of the loop: tools/attn_ablate.py, profiles/r3_attn_ablation.txt)
+  constexpr int NT = 64 * NW;
+  constexpr int KT = 64, NKB = 2, VCH = KT / 8;
+  constexpr int KSLOTS = (2 * KS) | 1;
+  constexpr int KCH = 2 * KS;
+  constexpr int DV = NB * 32;
+  constexpr int VROW = KT * 2 + 16;            // 144 B = 9 slots of 16 B (odd): conflict-free ds_read_b128
+  constexpr int K_BYTES = KT * KSLOTS * 16;
+  constexpr int V_BYTES = DV * VROW;
+  constexpr int BUF = K_BYTES + V_BYTES;
+  constexpr int NCH_K = (KT * KCH + NT - 1) / NT;
+  constexpr int NCH_V = (DV * VCH + NT - 1) / NT;
+  constexpr float BIAS = 8.0f;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int grp = lin / (8 * gx), rr = lin - grp * 8 * gx;
+  const int gsz = min(8, nbh - grp * 8);
+  const int bh = grp * 8 + rr % gsz, xq = rr / gsz;
+  const int head = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
+  const int D = p.D, D8 = D >> 3;
+  const int q0 = xq * (32 * NW) + wave * 32;
+  const int qi = q0 + r;
+
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int d = 16 * s + 8 * h;
+    qf[s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kp), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned kInv = 0x80000000u;
+  unsigned koff[NCH_K], voff[NCH_V];
+  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_kc[NCH_V];
+#pragma unroll
+  for (int i = 0; i < NCH_K; ++i) {
+    const int q = tid + NT * i;
+    const int key = q / KCH, ch = q - key * KCH;
+    k_key[i] = key;
+    k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
+    koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH_V; ++i) {
+    const int q = tid + NT * i;
+    const int d = q / VCH, kc = q - d * VCH;
+    v_kc[i] = kc;
+    v_lds[i] = (q < DV * VCH && d < D) ? d * VROW + (kc >> 1) * 32 + (kc & 1) * 8 : -1;   // key permutation: see v2
+    voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
+  }
+  for (int q = tid; q < DV * VCH; q += NT) {
+    const int d = q / VCH, kc = q - d * VCH;
+    if (d >= D) {
+      const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf)
+        *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + d * VROW + kc * 16) = u32x4{fill, fill, fill, fill};
+    }
+  }
+  // two staging register sets: tile t+4 is requested at step t and written to LDS at step t+2 (one step of
+  // flight time is less than the L2 latency under load)
+  u32x4 kregA[NCH_K], vregA[NCH_V], kregB[NCH_K], vregB[NCH_V];
+  auto load_tile = [&](int key0, u32x4 (&kreg)[NCH_K], u32x4 (&vreg)[NCH_V]) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i) {
+      unsigned o = koff[i];
+      if (tail && key0 + k_key[i] >= p.nk) o = kInv;
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)o, (int)sk, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      unsigned o = voff[i];
+      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+    }
+  };
+  auto store_tile = [&](int key0, unsigned char* buf, const u32x4 (&kreg)[NCH_K], const u32x4 (&vreg)[NCH_V]) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    unsigned char* ksm = buf;
+    unsigned char* vsm = buf + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i)
+      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      if (v_lds[i] >= 0) {
+        u32x4 v = vreg[i];
+        if (tail) {
+          const int nvalid = p.nk - (key0 + v_kc[i] * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
+            v[e] &= keep;
+          }
+        }
+        u32x2* dst = reinterpret_cast<u32x2*>(vsm + v_lds[i]);
+        dst[0] = u32x2{v.x, v.y};
+        dst[2] = u32x2{v.z, v.w};
+      }
+    }
+  };
+
+  f32x16 acc_o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[nb][i] = 0.f;
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  float l_run = 0.f;
+
+  const int ntiles = (p.nk + KT - 1) / KT;
+
+  // S(t) = K(t) Q - m from ring slot t & 3, with the tail mask
+  auto qk_tile = [&](int t, f32x16 (&S)[NKB]) __attribute__((always_inline)) {
+    const unsigned char* ksm = smem + (t & 3) * BUF;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * s + h) * 16);
+        S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]),
+                                                        s == 0 ? negm : S[kb], 0, 0, 0);
+      }
+  };
+  auto mask_tail = [&](int t, f32x16 (&S)[NKB]) __attribute__((always_inline)) {
+    const int key0 = t * KT;
+    if (key0 + KT > p.nk) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= p.nk) S[kb][i] = -INFINITY;
+        }
+    }
+  };
+  auto pv_tile = [&](int t, const unsigned (&P)[NKB][8]) __attribute__((always_inline)) {
+    const unsigned char* vsm = smem + (t & 3) * BUF + K_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NKB; ++ks) {
+      const int kb = ks >> 1, half = ks & 1;
+      const u32x4 pf = {P[kb][4 * half + 0], P[kb][4 * half + 1], P[kb][4 * half + 2], P[kb][4 * half + 3]};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4 vf = *reinterpret_cast<const u32x4*>(vsm + (nb * 32 + r) * VROW + ks * 32 + 16 * h);
+        acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+      }
+    }
+  };
+
+  // one step: exp(t) on the VALU beside PV(t-1) + QK(t+1) on the matrix pipe.  has_prev / has_next are compile-time
+  // (first / last steps are peeled) so that the two streams sit in ONE basic block the scheduler can interleave.
+  auto step = [&](auto hp, auto hn, int t, f32x16 (&Sc)[NKB], f32x16 (&Sn)[NKB], const unsigned (&Pp)[NKB][8],
+                  unsigned (&Pc)[NKB][8], u32x4 (&kreg)[NCH_K], u32x4 (&vreg)[NCH_V]) __attribute__((always_inline)) {
+    constexpr bool has_prev = decltype(hp)::value, has_next = decltype(hn)::value;
+    if (t > 0 && !(ABL & 8)) __syncthreads();        // tile t+1 is in LDS for everyone; everyone is done with tile t-2
+    if (t + 2 < ntiles && !(ABL & 8)) {
+      store_tile((t + 2) * KT, smem + ((t + 2) & 3) * BUF, kreg, vreg);
+      if (t + 4 < ntiles) load_tile((t + 4) * KT, kreg, vreg);
+    }
+    // only the last tile can hold keys >= nk, and the last step is a peeled one: the steady step stays branch-free
+    if constexpr (has_prev && !has_next) mask_tail(t, Sc);
+    unsigned orv = 0u;
+    float psum = 0.f;
+    auto exp_unit = [&](int u) __attribute__((always_inline)) {      // two scores -> one packed register
+      const int kb = u >> 3, j = u & 7;
+      const float p0 = (ABL & 1) ? Sc[kb][2 * j] : __builtin_amdgcn_exp2f(Sc[kb][2 * j]);
+      const float p1 = (ABL & 1) ? Sc[kb][2 * j + 1] : __builtin_amdgcn_exp2f(Sc[kb][2 * j + 1]);
+      if (!ONES) psum += p0 + p1;
+      Pc[kb][j] = pack2(p0, p1);
+      orv |= (ABL & 1) ? 0u : Pc[kb][j];
+    };
+    if constexpr (has_prev && has_next) {
+      // The steady step, dealt by hand into ONE issue order (sched_barrier(0) pins it; the sched_group_barrier form left
+      // the MFMAs clustered at both ends): per MFMA slot [MFMA i | LDS read of the operand of MFMA i+2 | its share of the
+      // 8*NKB exponential units].  MFMA i: PV of tile t-1 for i < NPV (ks = i / NB, nb = i % NB), then QK of tile t+1.
+      constexpr int NPV = 2 * NKB * NB, NM = NPV + NKB * KS, NU = 8 * NKB;
+      const unsigned char* vsm = smem + ((t - 1) & 3) * BUF + K_BYTES;
+      const unsigned char* ksm = smem + ((t + 1) & 3) * BUF;
+      auto frag = [&](int i) __attribute__((always_inline)) -> u32x4 {
+        if (ABL & 4) return u32x4{(unsigned)i, 0x3f803f80u, (unsigned)lane, 0x3f803f80u};
+        if (i < NPV) return *reinterpret_cast<const u32x4*>(vsm + ((i % NB) * 32 + r) * VROW + (i / NB) * 32 + 16 * h);
+        const int q = i - NPV, kb = q / KS, sx = q - kb * KS;
+        return *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * sx + h) * 16);
+      };
+      u32x4 fr[3];
+      fr[0] = frag(0);
+      fr[1] = frag(1);
+      int u = 0;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i + 2 < NM) fr[(i + 2) % 3] = frag(i + 2);
+        if (i < NPV) {
+          const int ks = i / NB, nb = i % NB, kb = ks >> 1, half = ks & 1;
+          const u32x4 pf = {Pp[kb][4 * half + 0], Pp[kb][4 * half + 1], Pp[kb][4 * half + 2], Pp[kb][4 * half + 3]};
+          if (ABL & 2) { asm volatile("" ::"v"(fr[i % 3]), "v"(pf)); }
+          else acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % 3]), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+        } else {
+          const int q = i - NPV, kb = q / KS, sx = q - kb * KS;
+          if (ABL & 2) { asm volatile("" ::"v"(fr[i % 3])); if (sx == 0) Sn[kb] = negm; }
+          else Sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % 3]), __builtin_bit_cast(bf16x8, qf[sx]),
+                                                                sx == 0 ? negm : Sn[kb], 0, 0, 0);
+        }
+        const int nu = NU / NM + (i < NU % NM ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < nu; ++k) exp_unit(u++);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if constexpr (has_prev) pv_tile(t - 1, Pp);
+      if constexpr (has_next) qk_tile(t + 1, Sn);
+#pragma unroll
+      for (int u = 0; u < 8 * NKB; ++u) exp_unit(u);
+    }
+    if (__any(t == 0 || (orv & 0x40004000u) != 0u)) {
+      float mx = Sc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, Sc[kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float delta = t == 0 ? mx + BIAS : fmaxf(mx + BIAS, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] += -delta;
+      if (t != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        if (!ONES) l_run *= alpha;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o[nb][i] *= alpha;
+      }
+      if (has_next) {                                // S(t+1) was taken against the old level
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Sn[kb][i] -= delta;
+      }
+      psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(Sc[kb][2 * j] - delta), p1 = __builtin_amdgcn_exp2f(Sc[kb][2 * j + 1] - delta);
+          if (!ONES) psum += p0 + p1;
+          Pc[kb][j] = pack2(p0, p1);
+        }
+    }
+    if (!ONES) l_run += psum;
+  };
+
+  // prologue: tiles 0 and 1 in LDS, tile 2 in registers, S(0)
+  load_tile(0, kregA, vregA);
+  if (ntiles > 1) load_tile(KT, kregB, vregB);
+  store_tile(0, smem, kregA, vregA);
+  if (ntiles > 2) load_tile(2 * KT, kregA, vregA);     // set A: even tiles (stored by the even steps)
+  if (ntiles > 1) store_tile(KT, smem + BUF, kregB, vregB);
+  if (ntiles > 3) load_tile(3 * KT, kregB, vregB);     // set B: odd tiles
+  __syncthreads();
+  f32x16 S0[NKB], S1[NKB];
+  unsigned P0[NKB][8], P1[NKB][8];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P0[kb][j] = P1[kb][j] = 0u;
+  qk_tile(0, S0);
+  mask_tail(0, S0);
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  unsigned long long st0 = 0, sr0 = 0;
+  if (ABL & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+  if (ntiles > 1) step(F_{}, T_{}, 0, S0, S1, P1, P0, kregA, vregA);
+  else step(F_{}, F_{}, 0, S0, S1, P1, P0, kregA, vregA);
+  for (int t = 1; t + 1 < ntiles; t += 2) {          // steady steps 1 .. ntiles-2
+    step(T_{}, T_{}, t, S1, S0, P0, P1, kregB, vregB);
+    if (t + 2 < ntiles) step(T_{}, T_{}, t + 1, S0, S1, P1, P0, kregA, vregA);
+  }
+  if (ntiles > 1) {
+    const int last = ntiles - 1;
+    if (last & 1) step(T_{}, F_{}, last, S1, S0, P0, P1, kregB, vregB);
+    else step(T_{}, F_{}, last, S0, S1, P1, P0, kregA, vregA);
+  }
+  if ((ntiles - 1) & 1) pv_tile(ntiles - 1, P1);
+  else pv_tile(ntiles - 1, P0);
+  if ((ABL & 16) && tid == 0) {
+    // diagnostics: the tool's output allocation extends 16 bytes per workgroup beyond batch * sob elements
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<bf16_t*>(p.o) + (long long)p.batch * p.sob) + 2 * lin;
+    dbg[0] = __builtin_amdgcn_s_memtime() - st0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+  }
+
+  float l_tot;
+  if (ONES) {
+    float lsel = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * nb + 8 * g == D) lsel = acc_o[nb][4 * g];
+    l_tot = __shfl(lsel, r, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
+  const float inv = 1.0f / l_tot;
+  if (qi < p.nq) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * nb + 8 * g + 4 * h;
+        if (d < D) {
+          float v[4] = {acc_o[nb][4 * g + 0] * inv, acc_o[nb][4 * g + 1] * inv, acc_o[nb][4 * g + 2] * inv,
+                        acc_o[nb][4 * g + 3] * inv};
+          Elem<bf16_t>::store4(O + (long long)qi * p.ldo + d, v);
+        }
+      }
+  }
+}
+
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
   SaspaAttnParams p = p0;
@@ -561,21 +917,50 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
   // 64-key tiles otherwise (cross-attention has 77 keys, d = 160 needs the registers for O^T)
   constexpr bool BIG_OK = KS <= 6;
   const bool big = BIG_OK && p.nk >= 512;
-  // A/B knobs (diagnostics): SASPA_ATTN_MODE=0 runs prescaled queries through the v1 loop (c = 1), =1 v2 with one
-  // LDS buffer, =2 v2 with two buffers / one barrier per tile
-  const char* me = getenv("SASPA_ATTN_MODE");   // read per launch: tools/attn_bench.py flips it inside one process
-  const int mode = me ? atoi(me) : 2;
+  // A/B knob (diagnostics; read per launch so that tools/attn_bench.py can flip it inside one process): SASPA_ATTN_MODE
+  //   unset: the dispatch rule below.  0: prescaled queries through the v1 loop (c = 1).  1 / 2: v2 with one LDS buffer /
+  //   with two buffers and one barrier per tile.  3 / 4: the software-pipelined v3 loop (8 waves = 256 queries per workgroup).
+  const char* me = getenv("SASPA_ATTN_MODE");
+  int mode = me ? atoi(me) : -1;
   if (p.flags & SASPA_ATTN_QPRESCALED) {
-    // v2 keeps S' and the packed P live together: 128-key tiles fit the 256-register budget (two waves per SIMD) up
-    // to d = 48, 64-key tiles up to d = 96; wider heads (SD-1.5's 16x16 / 8x8 levels, d = 160) run the v1 loop
+    // v2 / v3 keep S' and the packed P live together, which fits two waves per SIMD up to d = 96 (v3 at d = 96 only with
+    // the spare ones row); wider heads (SD-1.5's 16x16 / 8x8 levels, d = 160) and short key sequences (cross-attention:
+    // 77 keys = two tiles, the first of which always takes the slow path; 40 vs 44 us at level 0) run the v1 loop.
     constexpr bool V2_OK = KS <= 6;
-    // short key sequences (cross-attention: 77 keys = two tiles, the first of which always takes the slow path) are
-    // faster on the v1 loop (tools/attn_bench.py: 40 vs 44 us at level 0)
+    constexpr bool V3_OK = V2_OK && (KS <= 5 || 32 * NB > 16 * KS);
+    const dim3 grid8((p.nq + 255) / 256, p.heads, p.batch);
+    if (mode < 0) {
+      // measured (tools/attn_bench.py, profiles/r3_attn_bench.txt): the 8-wave v3 loop wins once its 256-query workgroups
+      // still give every CU two of them; below that v2's 128-query workgroups balance better
+      const long long wg8 = (long long)grid8.x * grid8.y * grid8.z;
+      mode = (V3_OK && !p.causal && wg8 >= 512) ? 4 : 2;
+    }
+    if ((mode == 3 || mode == 4) && (!V3_OK || p.causal)) mode = 2;
     if (mode == 0 || !V2_OK || !big) {
       p.scale = 0.6931471805599453f;       // the v1 loop multiplies by log2(e): net factor 1
     } else if constexpr (V2_OK) {
       constexpr int KTB = KS <= 3 ? 128 : 64;
 #define SASPA_V2(ONES_, DB_) hipLaunchKernelGGL((flash_attn_v2_kernel<KS, NB, ONES_, KTB, DB_>), grid, dim3(256), 0, s, p)
+      if constexpr (V3_OK) {
+        if (mode >= 3) {
+#ifdef SASPA_GEMM_ABLATION
+          if constexpr (KS == 3 && NB == 2) {
+            const char* ae = getenv("SASPA_ATTN_ABLATE");
+            const int abl = ae ? atoi(ae) : 0;
+#define SASPA_V3A(A_) case A_: hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8, A_>), grid8, dim3(512), 0, s, p); SASPA_CHECK_LAUNCH(); return 0;
+            switch (abl) {
+              SASPA_V3A(1) SASPA_V3A(2) SASPA_V3A(4) SASPA_V3A(8) SASPA_V3A(16) SASPA_V3A(14) SASPA_V3A(13) SASPA_V3A(11) SASPA_V3A(7)
+              default: break;
+            }
+#undef SASPA_V3A
+          }
+#endif
+          if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8>), grid8, dim3(512), 0, s, p);
+          else hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, false, 8>), grid8, dim3(512), 0, s, p);
+          SASPA_CHECK_LAUNCH();
+          return 0;
+        }
+      }
       const bool db = mode >= 2;
       if (p.D < 32 * NB) { if (db) SASPA_V2(true, true); else SASPA_V2(true, false); }
       else { if (db) SASPA_V2(false, true); else SASPA_V2(false, false); }

@@ -269,9 +269,15 @@ def _prescaled_q(qq, d):
 @pytest.mark.parametrize("d,heads,nq,nk,causal", [
     (40, 8, 200, 200, False), (80, 4, 300, 300, False), (160, 2, 256, 256, False), (64, 3, 77, 77, True),
     (40, 8, 130, 77, False), (8, 4, 64, 64, False), (16, 2, 33, 200, False), (32, 4, 128, 64, False),
-    (40, 2, 1024, 1024, False), (64, 2, 640, 1024, False), (48, 1, 100, 513, False)])
-def test_flash_attn_prescaled(dev, d, heads, nq, nk, causal):
-    """SASPA_ATTN_QPRESCALED (v2 loop: reference level on the MFMA C operand, OR-bit overflow check)."""
+    (40, 2, 1024, 1024, False), (64, 2, 640, 1024, False), (48, 1, 100, 513, False), (80, 2, 300, 1090, False),
+    (40, 1, 257, 2048 + 31, False)])
+@pytest.mark.parametrize("mode", ["1", "2", "4"])
+def test_flash_attn_prescaled(dev, monkeypatch, mode, d, heads, nq, nk, causal):
+    """SASPA_ATTN_QPRESCALED (v2 / v3 loops: reference level on the MFMA C operand, OR-bit overflow check; mode 3 = the
+    software-pipelined v3 loop).  Sequences below 512 keys take the v1 loop whatever the mode: run those once."""
+    if nk < 512 and mode != "4":
+        pytest.skip("short sequences do not depend on SASPA_ATTN_MODE")
+    monkeypatch.setenv("SASPA_ATTN_MODE", mode)
     dtype = torch.bfloat16
     bsz, c = 2, heads * d
     qs, qeff = _prescaled_q(_rand(bsz, nq, c, seed=21), d)
@@ -289,11 +295,13 @@ def test_flash_attn_prescaled(dev, d, heads, nq, nk, causal):
     assert_close(out.float().cpu(), ref, dtype, what=f"flash prescaled d={d} nq={nq} nk={nk}")
 
 
+@pytest.mark.parametrize("mode", ["2", "4"])
 @pytest.mark.parametrize("spike,shift", [(6.0, 0.0), (60.0, 0.0), (1.0, -40.0), (6.0, 25.0)])
-def test_flash_attn_prescaled_level_moves(dev, spike, shift):
+def test_flash_attn_prescaled_level_moves(dev, monkeypatch, mode, spike, shift):
     """The v2 loop only moves its reference level when some p reaches 2.0: force that at a late KV tile (spiked key), with
     logits far below / above zero (shift: every key gets a component along every query's common direction), and a spike
     large enough that exp2 of the stale level overflows to inf (60 x)."""
+    monkeypatch.setenv("SASPA_ATTN_MODE", mode)
     dtype = torch.bfloat16
     bsz, heads, d, n = 1, 1, 40, 512
     qq = _rand(bsz, n, d, seed=24)
@@ -303,6 +311,7 @@ def test_flash_attn_prescaled_level_moves(dev, spike, shift):
     kk[..., 0] = shift
     kk[0, 300] = qq[0, 5] * spike                    # query 5 meets a huge score in the 3rd 128-key tile
     kk[0, 450] = qq[0, 77] * spike * 1.5             # and query 77 in the 4th
+    kk[0, 511] = qq[0, 200] * spike * 2.0            # and query 200 at the very last key (v3: the peeled last step)
     qs, qeff = _prescaled_q(qq, d)
     kk = q(kk, dtype)
     ref = _ref_attn(qeff, kk, vv, heads)

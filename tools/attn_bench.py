@@ -2,7 +2,7 @@
 SD-1.5 level 0/1/2 self- and cross-attention at CFG batch 16; SDXL levels 1/2 (head dim 64) at batch 8.
 Columns: v1 = plain queries (scale applied per score); pre0 / pre1 / pre2 = prescaled queries (SASPA_ATTN_QPRESCALED)
 through the v1 loop / the v2 loop with one LDS buffer / the v2 loop with two buffers and one barrier per tile
-(SASPA_ATTN_MODE = 0 / 1 / 2).  usage: python tools/attn_bench.py [quick] [512x704]"""
+(SASPA_ATTN_MODE = 0 / 1 / 2); pre4 = the software-pipelined v3 loop, 8 waves per workgroup (mode 4); auto = the shipped dispatch rule.  usage: python tools/attn_bench.py [quick] [512x704]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
@@ -23,13 +23,15 @@ for (B, H, NQ, NK, D) in shapes:
     k = torch.randn(B, NK, C, device=dev).bfloat16()
     vt = torch.randn(B, C, ops.round8(NK), device=dev).bfloat16()
     out = torch.empty(B, NQ, C, device=dev, dtype=torch.bfloat16)
-    arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre1", qs, True, "1"), ("pre2", qs, True, "2")]
+    arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre2", qs, True, "2"), ("pre4", qs, True, "4"), ("auto", qs, True, "")]
     best = {a[0]: [] for a in arms}
     ref = None
     for rnd in range(ROUNDS + 1):
         for name, qq, pre, mode in arms:
-            if mode is not None:
+            if mode:
                 os.environ["SASPA_ATTN_MODE"] = mode
+            else:
+                os.environ.pop("SASPA_ATTN_MODE", None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(REP):

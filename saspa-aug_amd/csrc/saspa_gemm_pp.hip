@@ -209,8 +209,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     soff = (s0 ? cu : cu - p.c0) * SZ;
     soffw = ku * SZ;
     if (!UP) {
-      if (src != (s0 ? 0 : 1)) {
-        // (re)scale the per-lane offsets for this source's row pitch: once per tap and source, not per tile
+      if (!ONEBAR && src != (s0 ? 0 : 1)) {
+        // (re)scale the per-lane offsets for this source's row pitch: once per tap and source, not per tile.  (The
+        // one-barrier 3x3 loop has no register to spare for va[]: it re-derives the offset per piece, 2 VALU.)
         src = s0 ? 0 : 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -275,10 +276,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
       const bool ok = ((vb[PW ? 0 : s] >> tapbit) & 1) != 0;
       off = ok ? __umul24((unsigned)px, (unsigned)ldsz) + (unsigned)(kcs * 16) : kInvalid;
     } else if (PW) {
-      off = (unsigned)va[s];
+      if (ONEBAR) {                                    // no register to spare for va[]: row -> offset per piece (3 VALU)
+        const int m = bm * BM + arow0 + 32 * s;
+        off = __umul24((unsigned)(m < p.M ? m : 0), (unsigned)ldsz) + (unsigned)(kcs * 16);
+      } else {
+        off = (unsigned)va[s];
+      }
     } else {
       // bit 31 set (out of range -> zeros) iff this tap falls outside the image for this row
-      off = (((unsigned)vb[PW ? 0 : s] << bsh) & amask) | (unsigned)va[s];
+      const unsigned base = ONEBAR ? __umul24((unsigned)vb[PW ? 0 : s] & 0xffffffu, (unsigned)ldsz) + (unsigned)(kcs * 16) : (unsigned)va[s];
+      off = (((unsigned)vb[PW ? 0 : s] << bsh) & amask) | base;
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + buf + dma_a + s * 32 * 8), 16, (int)off, soff, 0, 0);
   };
@@ -360,27 +367,138 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 
     if (nk > 0) {
       if (ONEBAR) {
-        // ---- one barrier per K-tile, waves otherwise free-running: the two waves of a SIMD interleave
-        //      their MFMA blocks with each other's reads / DMA issue on their own ----
+        // ---- ONE barrier per phase, asymmetric programs (round 3) ----
+        // The ping-pong loop below spends two s_barriers per phase to hand the matrix pipe from one wave group to the
+        // other (8 per K-tile: 52-57 % MFMA busy against 93 % with the barriers ablated).  Here the two
+        // groups run DIFFERENT programs between the same single barrier per phase:
+        //     wm = 0:  barrier | fragment reads of slice P | DMA issue | MFMAs of slice P
+        //     wm = 1:  barrier | MFMAs of slice P (fragments read in the previous phase) | reads of slice P+1 | DMA issue
+        // so right after a barrier the wm = 1 wave of every SIMD owns the matrix pipe while its wm = 0 partner waits for
+        // LDS, and they swap roles half a phase later without any hand-off.  Hazards (slots and DMA schedule exactly as
+        // in the ping-pong loop): a slot is restaged one phase after its slice's phase -- wm = 0 read it in that phase
+        // (retired before its MFMAs, i.e. before the next barrier), wm = 1 a phase earlier; tile t+1 must be complete
+        // before wm = 1 reads its slice 0 / B fragments in phase 3 of tile t: counted vmcnt fences at the END of a phase,
+        // in front of the barrier after which the data is read (table below).
+        // DMA schedule of this loop (round 3): ALL weight pieces of tile t+2 leave in phases 1 - 2 of tile t (their slots
+        // are free after phase 0), the four activation slices in phases 1, 2, 3 and 0 -- every piece is 4 - 6 phases in
+        // flight, against 2 - 3 for the pieces that completed a tile in the first version of this loop (which lost 13 -
+        // 30 % to the ping-pong loop: the loop was waiting for DMA, profiles/r3_pp_ab_v1.txt).
+        constexpr int NB1 = (FN + 1) / 2;              // weight pieces issued in phase 1; the rest in phase 2
+        auto stage_p1 = [&](const int buf) __attribute__((always_inline)) {
+          stage_a(0, buf);
+#pragma unroll
+          for (int i = 0; i < NB1; ++i) stage_b(i, buf);
+        };
+        auto stage_p2 = [&](const int buf) __attribute__((always_inline)) {
+          stage_a(1, buf);
+#pragma unroll
+          for (int i = NB1; i < FN; ++i) stage_b(i, buf);
+        };
         begin_stage();
 #pragma unroll
         for (int s = 0; s < 4; ++s) stage_slice(s, cur);
+        begin_stage();
+        stage_p1(oth);
+        stage_p2(oth);
+        stage_a(2, oth);
+        wait_vm<3 + FN>();                             // tile 0 has landed; tile 1 (all but slice 3) stays in flight
+        __builtin_amdgcn_s_barrier();
 #ifdef SASPA_GEMM_ABLATION
         if (stamp) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
-        for (int t = 0; t < nk; ++t) {
-          wait_vm<0>();                                // this wave's share of tile t has landed
-          if (!(abl & 8)) __builtin_amdgcn_s_barrier();  // everyone's has; everyone is done reading tile t-1 (-> oth is free)
-          begin_stage();                               // tile t+1 -> oth, issued slice by slice between the MFMA blocks
-          phase(0, 0, oth, false);
-          phase(1, 1, oth, false);
-          phase(2, 2, oth, false);
-          phase(3, 3, oth, false);
+        auto read_b = [&]() __attribute__((always_inline)) {
+          const int o1 = rb0 ^ 4;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            wb[j][0] = lds[rb0 + j * 16 * 8];
+            wb[j][1] = lds[o1 + j * 16 * 8];
+          }
+        };
+        auto read_a = [&](const int P) __attribute__((always_inline)) {
+          const int o1 = ra0 ^ 4;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            xa[i][0] = lds[ra0 + (P * 32 + i * 16) * 8];
+            xa[i][1] = lds[o1 + (P * 32 + i * 16) * 8];
+          }
+        };
+        auto mfma_block = [&](const int P) __attribute__((always_inline)) {
+          if (abl & 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { asm volatile("" ::"v"(xa[i][0])); asm volatile("" ::"v"(xa[i][1])); }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(wb[j][0])); asm volatile("" ::"v"(wb[j][1])); }
+            return;
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < FN; ++j) mma(wb[j][kk], xa[i][kk], acc[P * 2 + i][j]);
+          __builtin_amdgcn_s_setprio(0);
+        };
+        auto swap_bufs = [&]() __attribute__((always_inline)) {
           const int d = oth - cur;
-          ra0 += d; ra1 += d; rb0 += d; rb1 += d;
+          ra0 += d; rb0 += d;
           cur += d;
           oth -= d;
+        };
+        // one loop body for both groups (wave-uniform scalar branches): two copies of the loop spilled inside it
+        // `wm` (an SGPR integer) is tested at every site: a bool carried across the loop was kept in a VGPR and spilled
+        // wm = 1 ("lead"): MFMAs first, reads of the NEXT slice afterwards
+        if (wm != 0) { read_b(); read_a(0); }
+        // counted waits (issue order is program order; c0..c3 = pieces a wave issues in phases 0..3 = 1, 1 + NB1,
+        // 1 + FN - NB1, 1): a fence sits at the END of a phase, in front of the barrier after which the wm = 1 group reads
+        //   end of phase 2: B + slices 0, 1 of tile t+1 (issued up to phase 2 of tile t-1) -> all but c3+c0+c1+c2 = 4 + FN
+        //   end of phase 0: slice 2 of tile t (issued in phase 3 of tile t-2)             -> all but 2c0+c1+c2+c3 = 5 + FN
+        //   end of phase 1: slice 3 of tile t (issued in phase 0 of tile t-1)             -> all but c0+2c1+c2+c3 = 5 + FN + NB1
+        // ablation hooks (diagnostics build only; plain statements otherwise)
+#ifdef SASPA_GEMM_ABLATION
+#define BAR() do { if (!(abl & 8)) __builtin_amdgcn_s_barrier(); } while (0)
+#define RD(...) { if (!(abl & 2)) { __VA_ARGS__ } }
+#define ST(...) { if (!(abl & 4)) { __VA_ARGS__ } }
+#else
+#define BAR() __builtin_amdgcn_s_barrier()
+#define RD(...) { __VA_ARGS__ }
+#define ST(...) { __VA_ARGS__ }
+#endif
+        for (int t = 0; t < nk; ++t) {
+          // ---- phase 0 ----
+          BAR();
+          if (wm == 0) { RD(read_b(); read_a(0);) ST(stage_a(3, oth);) }
+          mfma_block(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wm != 0) { RD(read_a(1);) ST(stage_a(3, oth);) }
+          wait_vm<5 + FN>();
+          begin_stage();
+          // ---- phase 1 ----
+          BAR();
+          if (wm == 0) { RD(read_a(1);) ST(stage_p1(cur);) }
+          mfma_block(1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wm != 0) { RD(read_a(2);) ST(stage_p1(cur);) }
+          wait_vm<5 + FN + NB1>();
+          // ---- phase 2 ----
+          BAR();
+          if (wm == 0) { RD(read_a(2);) ST(stage_p2(cur);) }
+          mfma_block(2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wm != 0) { RD(read_a(3);) ST(stage_p2(cur);) }
+          wait_vm<4 + FN>();
+          // ---- phase 3 ----
+          BAR();
+          if (wm == 0) { RD(read_a(3);) ST(stage_a(2, cur);) }
+          mfma_block(3);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wm != 0) { ST(stage_a(2, cur);) }
+          swap_bufs();
+          if (wm != 0) { RD(read_b(); read_a(0);) }        // tile t+1 (zeros past the K range): complete since this phase's barrier
         }
+#undef BAR
+#undef RD
+#undef ST
 #ifdef SASPA_GEMM_ABLATION
         if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -612,6 +730,13 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
 
 int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn) {
   if (!saspa_gemm_pp_eligible(p)) return SASPA_ERANGE;
+  // K loop flavour: SASPA_GEMM_PP_LOOP=1 selects the one-barrier-per-phase asymmetric loop (fn 14 / 15) instead of the
+  // two-barrier ping-pong loop.  Built and measured in round 3 (tools/pp_ab.py, profiles/r3_pp_ab_v*.txt): bit-identical
+  // and 12 - 30 % SLOWER on every shape, with either DMA schedule -- kept as an opt-in A/B arm, read per launch.
+  if (fn == 4 || fn == 5) {
+    const char* e = getenv("SASPA_GEMM_PP_LOOP");
+    if (e && atoi(e) == 1) fn += 10;
+  }
   if (fn == 5) return launch_pp<5, false>(p, s, ksplit);
   if (fn == 4) return launch_pp<4, false>(p, s, ksplit);
   if (fn == 15) return launch_pp<5, true>(p, s, ksplit);

@@ -28,10 +28,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" ".join(f"{v:9.1f}" for v in out))
 else:
     pp = sys.argv[1] if len(sys.argv) > 1 else "5"
+    loop = sys.argv[2] if len(sys.argv) > 2 else "1"     # SASPA_GEMM_PP_LOOP: 0 ping-pong, 1 asymmetric one-barrier loop
+    print("SASPA_GEMM_PP_LOOP =", loop)
     print(f"PP={pp} variant                          conv 65536x320x5760   conv 131072x512x4608   lin 65536x1280x1280  (us)")
     for name, abl in (("full", 0), ("no MFMA", 1), ("no LDS reads (MFMA on stale regs)", 2), ("no DMA", 4), ("no barriers", 8),
                       ("DMA + barriers only", 3), ("MFMA + barriers only", 6), ("reads + barriers only", 5), ("barriers only", 7),
                       ("MFMA only", 14)):
-        env = dict(os.environ, SASPA_GEMM_ABLATE=str(abl), SASPA_GEMM_PP=pp)
+        env = dict(os.environ, SASPA_GEMM_ABLATE=str(abl), SASPA_GEMM_PP=pp, SASPA_GEMM_PP_LOOP=loop)
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         print(f"{name:40s} {r}")

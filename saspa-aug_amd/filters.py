@@ -278,30 +278,61 @@ def load_clip_rn50(path):
     return {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
 
 
+def synthetic_filters_allowed():
+    """Opt-in for architecture-exact SYNTHETIC filter weights (tests, benchmarks): SASPA_SYNTHETIC_FILTERS=1."""
+    return os.environ.get("SASPA_SYNTHETIC_FILTERS", "0") not in ("", "0")
+
+
+def filter_checkpoints(ds_utils, weights_dir, semantic=True, confidence=True):
+    """Paths of the checkpoints the enabled filters need: (clip RN50 path | None, baseline checkpoint path | None).
+    Raises FileNotFoundError for a missing / ambiguous checkpoint unless synthetic filter weights were asked for
+    explicitly -- a filtered aug.json must never reflect the decisions of random models (the reference asserts exactly
+    one baseline checkpoint, all_utils/dataset_utils.py:92, and loads the real CLIP, all_utils/utils.py:253)."""
+    name = "compcars" if "compcars" in ds_utils.name else ds_utils.name
+    rn = cp = None
+    if semantic:
+        cand = os.path.join(weights_dir, "clip", "RN50.pt") if weights_dir else None
+        if cand and os.path.exists(cand):
+            rn = cand
+        elif not synthetic_filters_allowed():
+            raise FileNotFoundError(
+                f"semantic filter: {cand or '<WEIGHTS_DIR>/clip/RN50.pt'} not found.  Give WEIGHTS_DIR with the OpenAI CLIP RN50 "
+                "checkpoint, set SEMANTIC_FILTERING = 0, or opt in to synthetic filter weights with SASPA_SYNTHETIC_FILTERS=1")
+    if confidence:
+        cdir = Path(weights_dir, "checkpoints", name) if weights_dir else None
+        cps = sorted(cdir.glob("*.pth")) if cdir else []
+        if len(cps) > 1:
+            raise FileNotFoundError(f"Found {len(cps)} checkpoints in {cdir}. Expected 1")
+        if cps:
+            cp = str(cps[0])
+        elif not synthetic_filters_allowed():
+            raise FileNotFoundError(
+                f"model-confidence filter: no baseline checkpoint (*.pth) in {cdir or '<WEIGHTS_DIR>/checkpoints/' + name}.  Train the "
+                "baseline first (fgvc/train.py), set MODEL_CONFIDENCE_BASED_FILTERING = 0, or opt in to synthetic filter "
+                "weights with SASPA_SYNTHETIC_FILTERS=1")
+    return rn, cp
+
+
 def build_filters(ds_utils, dev, semantic=True, confidence=True, weights_dir=None, top_k=10, tokenizer=None):
     """The filter models for a dataset.  `weights_dir` holds `clip/RN50.pt` and `checkpoints/<dataset>/*.pth` (the
-    reference's `all_utils/checkpoints/<name>/`); without it the stage runs on architecture-exact SYNTHETIC weights (like
-    the generator does without checkpoints) and says so -- decisions are then those of random models."""
+    reference's `all_utils/checkpoints/<name>/`).  A missing checkpoint is an error (filter_checkpoints); only with
+    SASPA_SYNTHETIC_FILTERS=1 does the stage run on architecture-exact SYNTHETIC weights, and says so loudly."""
     from .tokenizer import make_tokenizer
     sem = conf = None
-    name = "compcars" if "compcars" in ds_utils.name else ds_utils.name
+    rn, cp = filter_checkpoints(ds_utils, weights_dir, semantic, confidence)
     if semantic:
-        rn = os.path.join(weights_dir, "clip", "RN50.pt") if weights_dir else None
-        if rn and os.path.exists(rn):
+        if rn:
             sd = load_clip_rn50(rn)
         else:
-            logging.info("semantic filter: no clip/RN50.pt under WEIGHTS_DIR -> SYNTHETIC CLIP-RN50 weights")
+            logging.warning("semantic filter: SASPA_SYNTHETIC_FILTERS=1 -> SYNTHETIC CLIP-RN50 weights; its decisions are those of a random model")
             sd = W.synth_state_dict("clip_rn50", CLIP_RN50, 11)
         tok = tokenizer or make_tokenizer(os.path.join(weights_dir, "clip") if weights_dir else None, CLIP_RN50["vocab"], pad_id=0)
         sem = SemanticFilter(sd, CLIP_RN50, dev, ds_utils.get_basic_prompt(), tok)
     if confidence:
-        cps = sorted(Path(weights_dir, "checkpoints", name).glob("*.pth")) if weights_dir else []
-        if len(cps) > 1:
-            raise FileNotFoundError(f"Found {len(cps)} checkpoints in {Path(weights_dir, 'checkpoints', name)}. Expected 1")
-        if cps:
-            sd, cfg = load_cal_checkpoint(str(cps[0]))
+        if cp:
+            sd, cfg = load_cal_checkpoint(cp)
         else:
-            logging.info("confidence filter: no baseline checkpoint under WEIGHTS_DIR -> SYNTHETIC WSDAN_CAL (resnet101) weights")
+            logging.warning("confidence filter: SASPA_SYNTHETIC_FILTERS=1 -> SYNTHETIC WSDAN_CAL (resnet101) weights; its decisions are those of a random model")
             cfg = dict(WSDAN_CAL_R101, num_classes=max(2, ds_utils.num_classes))
             sd = W.synth_state_dict("cal", cfg, 12)
         conf = ConfidenceFilter(sd, cfg, dev, top_k)
@@ -317,11 +348,25 @@ def _load_u8(path):
         return np.asarray(im.convert("RGB"))
 
 
+def _image_size(path):
+    from PIL import Image
+    with Image.open(path) as im:      # header only: nothing is decoded
+        return im.size[1], im.size[0]
+
+
 def apply_filters(mapping, original_images_paths, ds_utils, dev, semantic=None, confidence=None, batch_size=32):
     """mapping: {original file name: [augmented paths]} as `match_augmented_images` builds it (every original present).
     Returns (filtered mapping, counters).  Per original image the reference first drops the augmentations whose
     classifier top-k misses the source label, then those CLIP does not recognise as the meta class; both decisions are
-    per augmented image and independent, so they are evaluated in batches (grouped by image size) and combined."""
+    per augmented image and independent, so they are evaluated in batches (grouped by image size) and combined.
+    Memory: a first pass reads only the PNG headers to group the paths by size; pixels are decoded per batch on a
+    prefetch thread, so at most two batches are resident on the host (a real dataset has 13-16k augmentations of ~1 MB)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if dev is None:
+        for m in (semantic, confidence):
+            if m is not None:
+                dev = m.dev
+                break
     labels = {}
     if confidence is not None:
         table = ds_utils.get_image_path_to_class_id_dict()
@@ -331,15 +376,19 @@ def apply_filters(mapping, original_images_paths, ds_utils, dev, semantic=None, 
     keep = {}
     counters = dict(not_in_top_k=0, semantic=0)
     groups = {}
-    images = {}
     for name, ap in work:
-        img = _load_u8(ap)
-        images[ap] = img
-        groups.setdefault(img.shape[:2], []).append((name, ap))
-    for _, items in sorted(groups.items()):
-        for i in range(0, len(items), batch_size):
-            chunk = items[i:i + batch_size]
-            batch = ops.h2d(torch.from_numpy(np.stack([images[ap] for _, ap in chunk])), dev)
+        groups.setdefault(_image_size(ap), []).append((name, ap))
+    chunks = [items[i:i + batch_size] for _, items in sorted(groups.items()) for i in range(0, len(items), batch_size)]
+
+    def decode(chunk):
+        return np.stack([_load_u8(ap) for _, ap in chunk])
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(decode, chunks[0]) if chunks else None
+        for ci, chunk in enumerate(chunks):
+            pixels = nxt.result()
+            nxt = pool.submit(decode, chunks[ci + 1]) if ci + 1 < len(chunks) else None
+            batch = ops.h2d(torch.from_numpy(pixels), dev)
             ok_c = confidence.passes(batch, [labels[name] for name, _ in chunk]) if confidence is not None else np.ones(len(chunk), bool)
             ok_s = semantic.passes(batch) if semantic is not None else np.ones(len(chunk), bool)
             for (name, ap), c_ok, s_ok in zip(chunk, ok_c, ok_s):

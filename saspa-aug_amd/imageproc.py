@@ -7,6 +7,7 @@ Mirrors what the reference's pipelines do on the CPU through `CLIPImageProcessor
 SURVEY 8a a7.9) and `BlipImageProcessor` (resize to 224 x 224 bicubic; a8).  The coefficient tables depend only on the
 sizes: they are computed once per (in, out, crop) on the host in double precision exactly as Pillow's
 `precompute_coeffs` / `normalize_coeffs_8bpc` do and cached on the device; all pixel arithmetic runs in the kernels."""
+import collections
 import math
 from functools import lru_cache
 
@@ -14,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _check_dev, _dt, _ptr, _stream
 
 PRECISION_BITS = 32 - 8 - 2
@@ -233,14 +235,24 @@ def cv_area_tables(ssize, dsize):
     return np.asarray(start, np.int32), np.asarray(si, np.int32), np.asarray(al, np.float32)
 
 
-_CV_DEV = {}
+_CV_DEV = collections.OrderedDict()
+_CV_DEV_MAX = 256          # (source size, target size, mode) table sets kept per process: real datasets have hundreds of sizes
 
 
 def _cv_dev(dev, key, build):
+    """Device copies of the host-built resize tables, LRU-bounded.  The upload goes through ops.h2d (pinned, non-blocking):
+    a pageable .to(dev) is a synchronous copy that waits for everything queued on the stream -- the previous batch's
+    whole step graph -- on every new source size."""
     k = (str(dev),) + key
-    if k not in _CV_DEV:
-        _CV_DEV[k] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in build())
-    return _CV_DEV[k]
+    hit = _CV_DEV.get(k)
+    if hit is not None:
+        _CV_DEV.move_to_end(k)
+        return hit
+    val = tuple(ops.h2d(torch.from_numpy(np.ascontiguousarray(a)), dev) for a in build())
+    _CV_DEV[k] = val
+    while len(_CV_DEV) > _CV_DEV_MAX:
+        _CV_DEV.popitem(last=False)
+    return val
 
 
 def cv_resize_u8(src, dh, dw, interpolation):

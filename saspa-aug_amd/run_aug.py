@@ -588,6 +588,11 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     aug_json_path = utils.get_aug_json_path(output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
                                             model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING)
     logging.info(f"Augmented json path will be at: \n{aug_json_path}")
+    if filter_models is None and (s.SEMANTIC_FILTERING or s.MODEL_CONFIDENCE_BASED_FILTERING):
+        # fail BEFORE hours of generation, not after: a filter flag with no checkpoint behind it is an error unless
+        # synthetic filter weights were asked for explicitly (SASPA_SYNTHETIC_FILTERS=1)
+        from . import filters as _filters
+        _filters.filter_checkpoints(ds_utils, s.WEIGHTS_DIR, bool(s.SEMANTIC_FILTERING), bool(s.MODEL_CONFIDENCE_BASED_FILTERING))
 
     blip = "blip_diffusion" in s.BASE_MODEL
     items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict,
@@ -688,10 +693,9 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
                     print(f"[loop] batch {bi}: drain of the previous batch {_time.time() - t2:.3f} s", flush=True)
                 if not ok and num_errors > 20:       # asynchronous failures surface here: same abort rule (:497-500)
                     logging.info("Too many errors, stopping generation on this rank")
-                    try:
-                        batch_generator.finish(handle)
-                    except RuntimeError as e:
-                        failed(batch, e)
+                    # the batch enqueued just now is drained like any other: written and marked when it succeeded,
+                    # counted as failed when it did not (it used to be finished and then dropped, status 0)
+                    drain((batch, handle, sources, subjects))
                     inflight = None
                     break
             inflight = (batch, handle, sources, subjects)
@@ -718,7 +722,8 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
         logging.info(f"Done Generating: {(status == 1).sum().item()} generated, {(status == -1).sum().item()} failed, "
                      f"{sum(i.skip for i in items)} skipped (already existed)")
         n_files = len(list(Path(output_folder).glob("*.*")))
-        fdev = torch.device(s.DEVICE) if (s.SEMANTIC_FILTERING or s.MODEL_CONFIDENCE_BASED_FILTERING) and filter_models is None else None
+        # the filter stage runs on this rank's GPU whether the models are built here or handed in
+        fdev = torch.device(s.DEVICE) if (s.SEMANTIC_FILTERING or s.MODEL_CONFIDENCE_BASED_FILTERING) else None
         json_path = utils.create_json_of_image_name_to_augmented_images_paths(
             ds_utils, output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
             model_confidence_based_filtering=s.MODEL_CONFIDENCE_BASED_FILTERING, init_log=False,

@@ -88,3 +88,26 @@ def test_run_aug_end_to_end_hed_control(dev, tmp_path):
     c = np.asarray(Image.open(ctrl[0]))
     # a grey-level soft edge map with three equal channels, not Canny's {0, 255}
     assert c.ndim == 3 and np.array_equal(c[..., 0], c[..., 1]) and len(np.unique(c)) > 8
+
+
+def test_run_aug_main_with_filter_models(dev, tmp_path):
+    """main(..., filter_models=(sem, conf)) with the filter flags set: the stage runs on s.DEVICE (it used to hand the
+    batches over on the CPU when the models were passed in) and the JSON carries the filtered name."""
+    from saspa_aug_amd import filters
+    from saspa_aug_amd.tokenizer import HashTokenizer
+    cfgs = CFG.tiny()
+    pipe = StableDiffusionControlNetPipeline(W.synth_family(cfgs, seed=3), cfgs).to("cuda:0", torch.float16)
+    s = _settings(tmp_path, "sd_v1.5")
+    s.SEMANTIC_FILTERING, s.MODEL_CONFIDENCE_BASED_FILTERING = 1, 1
+    ds = R.dataset_utils.DS_UTILS_DICT[s.DATASET](**s.DATASET_KWARGS)
+    cf = CFG.tiny_filters(num_classes=6)
+    sem = filters.SemanticFilter(W.synth_state_dict("clip_rn50", cf["clip_rn50"], 31), cf["clip_rn50"], dev, ds.get_basic_prompt(),
+                                 HashTokenizer(cf["clip_rn50"]["vocab"], pad_id=0))
+    conf = filters.ConfidenceFilter(W.synth_state_dict("cal", cf["cal"], 32), cf["cal"], dev, top_k=3)
+    res = R.main(s, ds_utils=ds, pipe=pipe, filter_models=(sem, conf))
+    assert (res["status"] == 1).all()
+    name = Path(res["json_path"]).name
+    assert "semantic_filtering" in name and "model_confidence_based_filtering_top_10_classes" in name
+    body = json.load(open(res["json_path"]))
+    assert len(body) == 5 and all(len(v) <= 2 for v in body.values())
+    assert all(Path(p).exists() for v in body.values() for p in v)

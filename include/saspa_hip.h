@@ -284,6 +284,10 @@ int saspa_safety_decide(const float* dots, int ldd, const float* gram, int ldg, 
  *   x0 = (x - r1 * e) * r0;  if r2: x = r3*last + r4*m0 + r5*m1 + r6*x0;  m1, m0, last = m0, x0, x;  x = r7*x + r8*m0 + r9*m1 */
 int saspa_cfg_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc, float guidance,
                          const float* row, const float* table, const int* index, void* stream);
+/* the same update without classifier-free guidance (sd_xl-turbo at guidance_scale 0 with sampler = "unipcmultistep",
+ * run_aug/run_aug.py:223-226, :567-571): eps / x are [nimg][hw][ldc], nothing is duplicated.  ABI 11. */
+int saspa_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc,
+                     const float* row, const float* table, const int* index, void* stream);
 
 /* SDEdit / img2img start latents (StableDiffusionControlNetImg2ImgPipeline.prepare_latents): per 8-channel
  * latent pixel, moments = AutoencoderKL.encode's quant_conv output (mean | logvar), e1 / e2 = the two generator draws:

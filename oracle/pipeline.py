@@ -110,15 +110,20 @@ class UniPC:
     scheduling_unipc_multistep.py, recalled).  The product derives closed-form per-step coefficients instead
     (saspa_aug_amd.scheduler.UniPCMultistepScheduler.plan); tests compare the two on arbitrary model outputs."""
 
-    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, solver_order=2, solver_type="bh2"):
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, solver_order=2, solver_type="bh2",
+                 spacing="leading"):
+        self.spacing = spacing                               # "trailing": built from the sdxl-turbo scheduler config
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.num_train, self.steps_offset, self.order, self.solver_type = num_train, steps_offset, solver_order, solver_type
         self.init_noise_sigma = 1.0
 
     def set_timesteps(self, n):
-        ratio = self.num_train // (n + 1)
-        ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        if self.spacing == "trailing":
+            ts = np.arange(self.num_train, 0, -self.num_train / n).round().copy().astype(np.int64) - 1
+        else:
+            ratio = self.num_train // (n + 1)
+            ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
         ac = self.alphas_cumprod.double().numpy()
         sig = np.sqrt((1 - ac) / ac)
         self.sigmas = torch.from_numpy(np.concatenate([np.interp(ts, np.arange(0, len(sig)), sig), [0.0]]))
@@ -267,6 +272,35 @@ def sd_controlnet_img2img_pipeline(weights, cfgs, ids_pos, ids_neg, source_u8, c
     return out
 
 
+@torch.no_grad()
+def sd_img2img_pipeline(weights, cfgs, ids_pos, ids_neg, source_u8, sample_noise, noise, steps, strength, guidance_scale=7.5,
+                        return_latents=False):
+    """StableDiffusionImg2ImgPipeline.__call__ -- the reference's CONTROLNET = None, SDEDIT = 1 branch
+    (run_aug/run_aug.py:163-165, :235-241, :274-276; Real-Guidance defaults run_aug/run_aug_real_guidance.py:520-523;
+    [upstream] diffusers 0.32.2): the img2img procedure of `sd_controlnet_img2img_pipeline` with every evaluation the UNet
+    alone.  PARITY UNPINNED (diffusers absent), like the ControlNet form it restates next to."""
+    ctx = M.clip_text_forward(weights["text"], cfgs["text"], torch.cat([ids_neg, ids_pos], 0))
+    src = torch.from_numpy(np.ascontiguousarray(source_u8)).float().permute(2, 0, 1)[None] / 127.5 - 1.0
+    mean, logvar = M.vae_encode(weights["vae"], cfgs["vae"], src)
+    std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+    x0 = (mean + std * sample_noise.float()) * cfgs["vae"]["scaling_factor"]
+    sch = DDIM()
+    ts_all = sch.set_timesteps(steps)
+    init = min(int(steps * strength), steps)
+    ts = ts_all[max(steps - init, 0):]
+    a_t = sch.alphas_cumprod[int(ts[0])]
+    x = a_t ** 0.5 * x0 + (1 - a_t) ** 0.5 * noise.float()
+    for t in ts:
+        eps2 = M.unet_forward(weights["unet"], cfgs["unet"], torch.cat([x, x], 0), int(t), ctx)
+        eps_u, eps_c = eps2.chunk(2)
+        x = sch.step(eps_u + guidance_scale * (eps_c - eps_u), t, x)
+    img = M.vae_decode(weights["vae"], cfgs["vae"], x / cfgs["vae"]["scaling_factor"])
+    out = postprocess(img)
+    if return_latents:
+        return out, x, img
+    return out
+
+
 def run_safety_checker(sd, cfg, images_u8):
     """StableDiffusionControlNetPipeline.run_safety_checker + the checker's black-out: u8 [B,H,W,3] ->
     (u8 images with flagged ones zeroed, flags)."""
@@ -316,7 +350,7 @@ def blip_controlnet_pipeline(weights, cfgs, ids_prompt, ids_neg, query_embeds, c
 
 @torch.no_grad()
 def sdxl_controlnet_pipeline(weights, cfgs, ids1, ids2, control_u8, latents, steps, conditioning_scale=0.75,
-                             return_latents=False, guidance_scale=0.0, neg_ids1=None, neg_ids2=None):
+                             return_latents=False, guidance_scale=0.0, neg_ids1=None, neg_ids2=None, sampler="ddim"):
     """StableDiffusionXLControlNetPipeline.__call__ as the reference invokes it for sd_xl-turbo
     (run_aug/run_aug.py:189-201, :223-228, :564-571): guidance_scale 0 -> NO classifier-free guidance (one
     conditional evaluation per step, no negative prompt), 2 steps, DDIMScheduler.from_config(<SDXL-Turbo scheduler
@@ -344,7 +378,8 @@ def sdxl_controlnet_pipeline(weights, cfgs, ids1, ids2, control_u8, latents, ste
         cond = torch.cat([cond, cond], 0)
     nb = ctx.shape[0]
     added = dict(text_embeds=pooled, time_ids=torch.tensor([[hh, ww, 0, 0, hh, ww]] * nb, dtype=torch.float32))
-    sch = DDIM(spacing="trailing")
+    # sampler "unipc": UniPCMultistepScheduler.from_config(<the same scheduler config>) (run_aug/run_aug.py:223-226)
+    sch = UniPC(spacing="trailing") if sampler == "unipc" else DDIM(spacing="trailing")
     x = latents.clone().float() * sch.init_noise_sigma
     for t in sch.set_timesteps(steps):
         xin = torch.cat([x, x], 0) if cfg else x

@@ -100,6 +100,7 @@ SYMBOLS = {
     "saspa_resize_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "saspa_vae_sample_noise": (_I, [_I, _P, _P, _P, _P, _LL, _F, _F, _F, _P]),
     "saspa_cfg_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P]),
+    "saspa_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void cfg_plms_kernel(const T* eps, T* x, T* hi
 // state = [last | m0 | m1], each [nimg][hw][8] in the activation dtype.  row = 12 floats, from the launch arguments or
 // from row *index of a device table (hipGraph replays).
 struct UniPcRow { float v[12]; };
-template <typename T>
+// CFG = false (sd_xl-turbo, guidance_scale 0): eps holds ONE evaluation per image and x is not duplicated
+template <typename T, bool CFG = true>
 __global__ __launch_bounds__(256) void cfg_unipc_kernel(const T* eps, T* x, T* state, int nimg, long long hw, int C, float g, UniPcRow row,
                                                         const float* table, const int* index) {
   const long long total = (long long)nimg * hw;
@@ -175,14 +176,14 @@ __global__ __launch_bounds__(256) void cfg_unipc_kernel(const T* eps, T* x, T* s
   for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
     float eu[8], ec[8], xv[8], lv[8], m0[8], m1[8], x0[8], o[8];
     load8(eps + it * 8, eu);
-    load8(eps + half + it * 8, ec);
+    if (CFG) load8(eps + half + it * 8, ec);
     load8(x + it * 8, xv);
     load8(m0p + it * 8, m0);
     load8(m1p + it * 8, m1);
     if (r[2] != 0.f) load8(last + it * 8, lv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = eu[j] + g * (ec[j] - eu[j]);
+      const float e = CFG ? eu[j] + g * (ec[j] - eu[j]) : eu[j];
       x0[j] = (xv[j] - r[1] * e) * r[0];
       float xc = xv[j];
       if (r[2] != 0.f) xc = r[3] * lv[j] + r[4] * m0[j] + r[5] * m1[j] + r[6] * x0[j];
@@ -194,8 +195,30 @@ __global__ __launch_bounds__(256) void cfg_unipc_kernel(const T* eps, T* x, T* s
     store8(m1p + it * 8, m0);
     store8(m0p + it * 8, x0);
     store8(x + it * 8, o);
-    store8(x + half + it * 8, o);
+    if (CFG) store8(x + half + it * 8, o);
   }
+}
+
+// the CFG-free form of saspa_cfg_unipc_step (sd_xl-turbo runs at guidance_scale 0: run_aug/run_aug.py:567-571, sampler
+// "unipcmultistep" :223-226): eps / x are [nimg][hw][8], state as below
+extern "C" int saspa_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc,
+                                const float* row, const float* table, const int* index, void* stream) {
+  if (!eps || !x || !state || nimg <= 0 || hw <= 0 || C <= 0 || (!row && !(table && index))) return SASPA_EINVAL;
+  if (ldc != 8 || C > 8) return SASPA_ERANGE;
+  if (!aligned16(eps) || !aligned16(x) || !aligned16(state)) return SASPA_EALIGN;
+  UniPcRow rr{};
+  if (row && !table)
+    for (int j = 0; j < 12; ++j) rr.v[j] = row[j];
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for((long long)nimg * hw);
+  if (dtype == SASPA_BF16)
+    hipLaunchKernelGGL((cfg_unipc_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)eps, (bf16_t*)x, (bf16_t*)state, nimg, hw, C, 0.f, rr, table, index);
+  else if (dtype == SASPA_F32)
+    hipLaunchKernelGGL((cfg_unipc_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)eps, (float*)x, (float*)state, nimg, hw, C, 0.f, rr, table, index);
+  else
+    return SASPA_EINVAL;
+  SASPA_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int saspa_cfg_unipc_step(int dtype, const void* eps, void* x, void* state, int nimg, long long hw, int C, int ldc,

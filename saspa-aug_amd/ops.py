@@ -539,6 +539,18 @@ def cfg_unipc_step(eps, x, state, nimg, hw, c, guidance, row=None, table=None, i
     return x
 
 
+def unipc_step(eps, x, state, nimg, hw, c, row=None, table=None, index=None):
+    """One UniPC step WITHOUT classifier-free guidance (sd_xl-turbo): eps / x [nimg, hw, 8]; state [3, nimg, hw, 8]."""
+    _check_dev(eps, x, state, table, index)
+    if table is not None and (table.dtype != torch.float32 or table.dim() != 2 or table.shape[1] != 12 or not table.is_contiguous()
+                              or index is None or index.dtype != torch.int32):
+        raise ValueError("unipc_step: table fp32 [steps, 12], int32 index")
+    r = None if row is None else (C.c_float * 12)(*[float(v) for v in row])
+    _lib.check(_lib.load().saspa_unipc_step(_dt(x), _ptr(eps), _ptr(x), _ptr(state), nimg, hw, c, 8, r, _ptr(table), _ptr(index),
+                                            _stream()), "saspa_unipc_step")
+    return x
+
+
 def index_add(index, delta=1):
     _check_dev(index)
     _lib.check(_lib.load().saspa_index_add(_ptr(index), int(delta), _stream()), "saspa_index_add")

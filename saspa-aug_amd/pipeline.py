@@ -65,7 +65,7 @@ class _StepGraph:
         if self.unipc:      # per-step coefficient rows; last sample + two x0-predictions in one static buffer
             self.evals = steps
             self.coefs = torch.zeros((steps, UniPCMultistepScheduler.ROW), device=dev, dtype=torch.float32)
-            self.state = torch.zeros((3, x_shape[0] // 2) + tuple(x_shape[1:]), device=dev, dtype=dt)
+            self.state = torch.zeros((3, x_shape[0] // 2 if cfg else x_shape[0]) + tuple(x_shape[1:]), device=dev, dtype=dt)
         elif self.plms:       # N + 1 evaluations; per-evaluation parameters, the 4-slot history ring and the saved sample
             self.evals = steps + 1
             self.coefs = torch.zeros((self.evals, 10), device=dev, dtype=torch.float32)
@@ -74,7 +74,7 @@ class _StepGraph:
         else:
             self.evals = steps
             self.coefs = torch.zeros((steps, 4), device=dev, dtype=torch.float32)
-        self.nets = (pipe.unet, pipe.controlnet)
+        self.nets = (pipe.unet,) if pipe.controlnet is None else (pipe.unet, pipe.controlnet)   # ControlNet-free: img2img baseline
         self.tables, self.curs, self.ctx_kv = [], [], []
         self.graph = None
         self.side = None                  # second capture stream of the forked step (fork_enabled)
@@ -125,7 +125,9 @@ class _StepGraph:
         pipe, x = self.pipe, self.x
         for net, tab, cur in zip(self.nets, self.tables, self.curs):
             ops.gather_row(tab, self.idx, cur)
-        if fork_enabled():
+        if pipe.controlnet is None:
+            mid2, skips2 = pipe.unet.encode(x, None)
+        elif fork_enabled():
             # the UNet encoder and the ControlNet encoder are independent until the zero convs add the two: two
             # branches of the captured graph.  Same kernels on the same inputs -> bit-identical to the single-stream order; what
             # changes is that one branch's launch gaps / tile tails / small deep-level kernels are filled by the other's work.
@@ -144,8 +146,10 @@ class _StepGraph:
         pipe.unet.decode(mid2, skips2, None, out=self.eps)
         nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
         nc, hw = pipe.cfgs["unet"]["out_channels"], x.shape[1] * x.shape[2]
-        if self.unipc:
+        if self.unipc and self.cfg:
             ops.cfg_unipc_step(self.eps, x, self.state, nimg, hw, nc, self.guidance, table=self.coefs, index=self.idx)
+        elif self.unipc:
+            ops.unipc_step(self.eps, x, self.state, nimg, hw, nc, table=self.coefs, index=self.idx)
         elif self.plms:
             ops.cfg_plms_step_dev(self.eps, x, self.hist, self.saved, nimg, hw, nc, self.guidance, self.coefs, self.idx)
         else:
@@ -180,6 +184,8 @@ class _StepGraph:
 
 
 class StableDiffusionControlNetPipeline:
+    HAS_CONTROLNET = True
+
     def __init__(self, state_dicts, cfgs=SD15, tokenizer=None, scheduler=None):
         self._state_dicts = state_dicts
         self.cfgs = cfgs
@@ -245,7 +251,7 @@ class StableDiffusionControlNetPipeline:
         sd, cf = self._state_dicts, self.cfgs
         fp8 = getattr(self, "_fp8", False) or os.environ.get("SASPA_FP8", "0") == "1"
         self.unet = models.UNet(sd["unet"], cf["unet"], device, cdt, fp8=fp8)
-        self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt, fp8=fp8)
+        self.controlnet = models.ControlNet(sd["controlnet"], cf["controlnet"], device, cdt, fp8=fp8) if self.HAS_CONTROLNET else None
         self.vae = models.VAEDecoder(sd["vae"], cf["vae"], device, cdt)
         self.text_encoder = models.CLIPText(sd["text"], cf["text"], device, cdt)
         self._build_extra(sd, cf, device, cdt)
@@ -325,20 +331,22 @@ class StableDiffusionControlNetPipeline:
                 ts, plan = list(sch.set_timesteps(steps))[t_start:], None
             x2.copy_(self._step_graph(x2, cemb2, ctx, len(ts) if t_start else steps, True, guidance_scale, cscale, ts).run_on(x2, cemb2, ctx, ts, plan=plan))
             return
-        self.unet.prepare_context(ctx)
-        self.controlnet.prepare_context(ctx)
+        nets = [self.unet] + ([self.controlnet] if self.controlnet is not None else [])
+        for net in nets:
+            net.prepare_context(ctx)
         eps = torch.zeros_like(x2)
 
         def evaluate(i):
             mid, skips = self.unet.encode(x2, i)
-            skips2, mid2 = self.controlnet.forward(x2, i, cemb2, cscale, skips, mid)
-            self.unet.decode(mid2, skips2, i, out=eps)
+            if self.controlnet is not None:
+                skips, mid = self.controlnet.forward(x2, i, cemb2, cscale, skips, mid)
+            self.unet.decode(mid, skips, i, out=eps)
 
         if isinstance(sch, PNDMScheduler):
             plan = sch.plan(steps)                     # N+1 evaluations, the second timestep twice
             ts = [t for t, _ in plan]
-            self.unet.prepare_timesteps(ts)
-            self.controlnet.prepare_timesteps(ts)
+            for net in nets:
+                net.prepare_timesteps(ts)
             hist = torch.zeros((4,) + tuple(x2[:b].shape), device=x2.device, dtype=x2.dtype)
             saved = None
             for i, (t, d) in enumerate(plan):
@@ -352,16 +360,16 @@ class StableDiffusionControlNetPipeline:
                 raise NotImplementedError("img2img with UniPC: the multistep history would have to start mid-schedule")
             plan = sch.plan(steps)
             ts = [t for t, _ in plan]
-            self.unet.prepare_timesteps(ts)
-            self.controlnet.prepare_timesteps(ts)
+            for net in nets:
+                net.prepare_timesteps(ts)
             state = torch.zeros((3,) + tuple(x2[:b].shape), device=x2.device, dtype=x2.dtype)
             for i, (t, row) in enumerate(plan):
                 evaluate(i)
                 ops.cfg_unipc_step(eps, x2, state, b, hw, nc, guidance_scale, row=row)
         else:
             ts = list(sch.set_timesteps(steps))[t_start:]
-            self.unet.prepare_timesteps(ts)
-            self.controlnet.prepare_timesteps(ts)
+            for net in nets:
+                net.prepare_timesteps(ts)
             for i, t in enumerate(ts):
                 evaluate(i)
                 ops.cfg_ddim_step(eps, x2, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
@@ -482,7 +490,10 @@ class StableDiffusionControlNetImg2ImgPipeline(StableDiffusionControlNetPipeline
                              f"steps is {kept} which is < 1 and not appropriate for this pipeline.")
         dev, dt = self.device, self.dtype
         to_dev = lambda a: ops.h2d(a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)), dev).contiguous()   # noqa: E731
-        src, ctrl = to_dev(source_u8), to_dev(control_u8)
+        if (control_u8 is None) != (self.controlnet is None):
+            raise ValueError("a control image is required by the ControlNet pipelines and refused by the ControlNet-free one")
+        src = to_dev(source_u8)
+        ctrl = to_dev(control_u8) if control_u8 is not None else src
         b, hh, ww, _ = ctrl.shape
         if tuple(src.shape) != tuple(ctrl.shape):
             raise ValueError("source and control images must have the same size")
@@ -502,9 +513,13 @@ class StableDiffusionControlNetImg2ImgPipeline(StableDiffusionControlNetPipeline
         if neg.shape[0] == 1 and b > 1:
             neg = neg.expand(b, -1, -1)
         ctx = torch.cat([neg, pos], 0).contiguous()
-        cemb = self.controlnet.cond_embedding(ops.u8_to_act(ctrl, dt))
+        if self.controlnet is not None:
+            cemb = self.controlnet.cond_embedding(ops.u8_to_act(ctrl, dt))
+            cemb2 = torch.cat([cemb, cemb], 0)
+        else:
+            cemb2 = torch.zeros((1,), device=dev, dtype=dt)           # placeholder: nothing reads it
         x2 = torch.cat([x, x], 0).contiguous()
-        self._sample(x2, b, (hh // 8) * (ww // 8), ctx, torch.cat([cemb, cemb], 0), num_inference_steps, guidance_scale,
+        self._sample(x2, b, (hh // 8) * (ww // 8), ctx, cemb2, num_inference_steps, guidance_scale,
                      controlnet_conditioning_scale, t_start=t_start)
         img = self.vae.decode(ops.scale(x2[:b], 1.0 / self.cfgs["vae"]["scaling_factor"]))
         out, self.last_nsfw = self.run_safety_checker(ops.act_to_u8(img))
@@ -529,6 +544,55 @@ class StableDiffusionControlNetImg2ImgPipeline(StableDiffusionControlNetPipeline
         neg = self.tokenizer(negative_prompt if negative_prompt is not None else "")
         out = self.generate_batch_img2img(ids, neg, src[None], ctrl[None], e1, e2, num_inference_steps, strength, guidance_scale,
                                           controlnet_conditioning_scale)
+        nsfw = None if self.last_nsfw is None else [bool(v) for v in self.last_nsfw.cpu().tolist()]
+        return PipelineOutput([Image.fromarray(a) for a in out.cpu().numpy()], nsfw)
+
+
+class StableDiffusionImg2ImgPipeline(StableDiffusionControlNetImg2ImgPipeline):
+    """Drop-in for diffusers' `StableDiffusionImg2ImgPipeline` -- the reference's CONTROLNET = None, SDEDIT = 1 branch
+    (run_aug/run_aug.py:163-165; the Real-Guidance baseline, defaults in run_aug/run_aug_real_guidance.py:520-523), called
+    as `pipe(prompt, image=<source PIL>, strength, num_inference_steps, generator, guidance_scale, negative_prompt)`
+    (:235-241, :274-276).  Same VAE-encode / posterior sample / add-noise / last int(steps * strength) DDIM steps as the
+    ControlNet img2img pipeline; every evaluation is the UNet alone (no ControlNet is built, no control image exists)."""
+    HAS_CONTROLNET = False
+
+    @classmethod
+    def from_pretrained(cls, base_dir, cfgs=SD15):
+        def f(d, *names):
+            for n in names:
+                p = os.path.join(d, n)
+                if os.path.exists(p):
+                    return W.load_safetensors(p)
+            raise FileNotFoundError(f"no safetensors weights in {d}")
+        w = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors")
+        sds = dict(unet=f(os.path.join(base_dir, "unet"), *w), vae=f(os.path.join(base_dir, "vae"), *w),
+                   text=f(os.path.join(base_dir, "text_encoder"), "model.safetensors", "model.fp16.safetensors"))
+        sc = os.path.join(base_dir, "safety_checker")
+        if "safety" in cfgs and os.path.isdir(sc):
+            sds["safety"] = f(sc, "model.safetensors", "model.fp16.safetensors")
+        return cls(sds, cfgs, tokenizer=make_tokenizer(os.path.join(base_dir, "tokenizer"), cfgs["text"]["vocab"]))
+
+    def generate_batch_img2img(self, prompt_ids, negative_ids, source_u8, sample_noise, noise, num_inference_steps, strength,
+                               guidance_scale=7.5, return_latents=False):
+        """source_u8: u8 [B,H,W,3] (numpy or device); sample_noise / noise: [B,4,H/8,W/8] CPU draws (posterior, add_noise)."""
+        return super().generate_batch_img2img(prompt_ids, negative_ids, source_u8, None, sample_noise, noise, num_inference_steps,
+                                              strength, guidance_scale, 0.0, return_latents)
+
+    def __call__(self, prompt=None, image=None, strength=0.8, num_inference_steps=50, generator=None, guidance_scale=7.5,
+                 negative_prompt=None, **unused):
+        self._need_device()
+        if image is None or prompt is None:
+            raise ValueError("`prompt` and `image` (the source image) are required")
+        src = np.asarray(image.convert("RGB") if isinstance(image, Image.Image) else image, dtype=np.uint8)
+        hh, ww = src.shape[:2]
+        if generator is not None and generator.device.type != "cpu":
+            raise NotImplementedError("the reference passes the global CPU generator (run_aug/run_aug.py:324)")
+        shape = (1, self.cfgs["unet"]["in_channels"], hh // 8, ww // 8)
+        e1 = torch.randn(shape, generator=generator, dtype=self.noise_dtype)             # latent_dist.sample(generator)
+        e2 = torch.randn(shape, generator=generator, dtype=self.noise_dtype)             # randn_tensor for add_noise
+        ids = self.tokenizer(str(prompt))
+        neg = self.tokenizer(negative_prompt if negative_prompt is not None else "")
+        out = self.generate_batch_img2img(ids, neg, src[None], e1, e2, num_inference_steps, strength, guidance_scale)
         nsfw = None if self.last_nsfw is None else [bool(v) for v in self.last_nsfw.cpu().tolist()]
         return PipelineOutput([Image.fromarray(a) for a in out.cpu().numpy()], nsfw)
 
@@ -771,22 +835,32 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
             x = torch.cat([x, x], 0).contiguous()
             cemb = torch.cat([cemb, cemb], 0)
         sch = self.scheduler
-        ts = sch.set_timesteps(num_inference_steps)
+        unipc = isinstance(sch, UniPCMultistepScheduler)        # run_aug/run_aug.py:223-226 with sampler = "unipcmultistep"
+        if unipc:
+            plan = sch.plan(num_inference_steps)
+            ts, rows = [t for t, _ in plan], [r for _, r in plan]
+        else:
+            ts, rows = sch.set_timesteps(num_inference_steps), None
         if graphs_enabled():
             g = self._step_graph(x, cemb, ctx, num_inference_steps, cfg, float(guidance_scale) if cfg else 0.0,
                                  controlnet_conditioning_scale, ts)
-            x = g.run_on(x, cemb, ctx, ts, (pooled, time_ids)).clone()
+            x = g.run_on(x, cemb, ctx, ts, (pooled, time_ids), plan=rows).clone()
         else:
             for net in (self.unet, self.controlnet):
                 net.prepare_context(ctx)
                 net.prepare_timesteps(ts, (pooled, time_ids))
             eps = torch.zeros_like(x)
             nc, hw = self.cfgs["unet"]["out_channels"], (hh // 8) * (ww // 8)
+            state = torch.zeros((3, b) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype) if unipc else None
             for i, t in enumerate(ts):
                 mid, skips = self.unet.encode(x, i)
                 skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
                 self.unet.decode(mid2, skips2, i, out=eps)
-                if cfg:
+                if unipc and cfg:
+                    ops.cfg_unipc_step(eps, x, state, b, hw, nc, guidance_scale, row=rows[i])
+                elif unipc:
+                    ops.unipc_step(eps, x, state, b, hw, nc, row=rows[i])
+                elif cfg:
                     ops.cfg_ddim_step(eps, x, b, hw, nc, guidance_scale, *sch.step_coefficients(t))
                 else:
                     ops.ddim_step(eps, x, b, hw, nc, *sch.step_coefficients(t))

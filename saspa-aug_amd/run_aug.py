@@ -251,16 +251,28 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
         else:
             logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
             pipe = StableDiffusionXLControlNetPipeline.from_synthetic(cfgs, seed=0)
-        if sampler != "ddim":
-            raise NotImplementedError("sd_xl-turbo runs on DDIM here (the CFG-free UniPC update is not built)")
-        pipe.scheduler = _scheduler_for(pipe)
+        pipe.scheduler = _scheduler_for(pipe)        # DDIM or UniPC, "trailing" spacing inherited from the sdxl-turbo config
         pipe.upcast_vae()
+        return pipe
+    if base_model == "sd_v1.5" and controlnet is None and SDEdit:
+        # run_aug/run_aug.py:163-165: StableDiffusionImg2ImgPipeline -- the Real-Guidance form (CONTROLNET = None, SDEDIT = 1;
+        # run_aug/run_aug_real_guidance.py:520-523), scheduler switched like every non-BLIP pipeline (:216-221)
+        from .pipeline import StableDiffusionImg2ImgPipeline
+        cfgs = cfgs or SD15
+        if state_dicts is not None:
+            pipe = StableDiffusionImg2ImgPipeline(state_dicts, cfgs)
+        elif weights_dir:
+            pipe = StableDiffusionImg2ImgPipeline.from_pretrained(os.path.join(weights_dir, BASE_MODEL_DICT[base_model]), cfgs)
+        else:
+            logging.info("no WEIGHTS_DIR given: using architecture-exact SYNTHETIC weights (no checkpoint available offline)")
+            pipe = StableDiffusionImg2ImgPipeline.from_synthetic(cfgs, seed=0)
+        pipe.scheduler = _scheduler_for(pipe)
         return pipe
     if base_model != "sd_v1.5" or controlnet not in CONTROLNET_DICT_SD:
         raise NotImplementedError(
-            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 (text-to-image and SDEdit img2img; canny or HED ControlNet), "
-            "blip_diffusion and sd_xl-turbo with the canny ControlNet are built; ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl are "
-            "baseline branches")
+            f"({base_model}, {controlnet}, SDEdit={SDEdit}): sd_v1.5 (text-to-image and SDEdit img2img with the canny or HED "
+            "ControlNet; ControlNet-free SDEdit img2img), blip_diffusion and sd_xl-turbo with the canny ControlNet are built; "
+            "ip2p / blip_diffusion-edit / sd_v2.1 / sd_xl and the ControlNet-free text-to-image pipelines are baseline branches")
     cfgs = cfgs or SD15
     if SDEdit:                                  # run_aug/run_aug.py:203-206: StableDiffusionControlNetImg2ImgPipeline
         from .pipeline import StableDiffusionControlNetImg2ImgPipeline as _Cls
@@ -284,8 +296,9 @@ def pass_thorugh_pipe(base_model, pipe, prompt, orig_img, SDEdit, SDEdit_strengt
     """Single-variant call form of the reference (name kept, typo included)."""
     pipe_args = {"prompt": str(prompt), "num_inference_steps": num_inference_steps, "generator": generator,
                  "guidance_scale": guidance_scale, "negative_prompt": negative_prompt}
-    if "ip2p" in base_model or base_model == "blip_diffusion-edit" or (SDEdit and control_image is None):
-        raise NotImplementedError("only the ControlNet call forms (text-to-image, SDEdit img2img, BLIP-Diffusion) are built")
+    if "ip2p" in base_model or base_model == "blip_diffusion-edit" or (control_image is None and not SDEdit):
+        raise NotImplementedError("built call forms: ControlNet text-to-image / SDEdit img2img / BLIP-Diffusion, and the "
+                                  "ControlNet-free SDEdit img2img (Real-Guidance)")
     if "blip_diffusion" in base_model:                     # run_aug/run_aug.py:243-250
         pipe_args["reference_image"] = orig_img
         pipe_args["source_subject_category"] = blip_src_category
@@ -490,7 +503,9 @@ def hip_batch_generator(pipe, s: Settings):
         """Everything of one batch up to the device-resident u8 images, WITHOUT waiting for the GPU.  `sources` /
         `subjects`: decoded images as loaded (lists; a stacked array when they already have the planned size)."""
         src = torch.stack([to_device(raw, it.height, it.width) for raw, it in zip(sources, batch)])
-        if hed is not None:                                                    # run_aug/run_aug.py:438-439
+        if not s.CONTROLNET:                                                   # run_aug/run_aug.py:435: no control image at all
+            ctrl = None
+        elif hed is not None:                                                  # run_aug/run_aug.py:438-439
             ctrl = hed.detect_batch(src)
         else:
             ctrl = ops.canny(src, s.LOW_THRESHOLD_CANNY, s.HIGH_THRESHOLD_CANNY)   # always from the ORIGINAL image (:437)
@@ -511,8 +526,12 @@ def hip_batch_generator(pipe, s: Settings):
         elif s.SDEDIT:
             # SDEdit (run_aug/run_aug.py:252-260, :274-276): img2img from the source image itself, two draws per item
             ids = np.concatenate([tok(it.prompt) for it in batch])
-            out = pipe.generate_batch_img2img(ids, neg_ids, src, ctrl, lat[0::2], lat[1::2], s.NUM_INFERENCE_STEPS,
-                                              s.SDEDIT_STRENGTH, s.GUIDANCE_SCALE, s.CONTROLNET_CONDITIONING_SCALE)
+            if ctrl is None:                               # Real-Guidance: StableDiffusionImg2ImgPipeline, UNet only
+                out = pipe.generate_batch_img2img(ids, neg_ids, src, lat[0::2], lat[1::2], s.NUM_INFERENCE_STEPS,
+                                                  s.SDEDIT_STRENGTH, s.GUIDANCE_SCALE)
+            else:
+                out = pipe.generate_batch_img2img(ids, neg_ids, src, ctrl, lat[0::2], lat[1::2], s.NUM_INFERENCE_STEPS,
+                                                  s.SDEDIT_STRENGTH, s.GUIDANCE_SCALE, s.CONTROLNET_CONDITIONING_SCALE)
         else:
             ids = np.concatenate([tok(it.prompt) for it in batch])
             out = pipe.generate_batch(ids, neg_ids, ctrl, lat, s.NUM_INFERENCE_STEPS, s.GUIDANCE_SCALE,
@@ -528,11 +547,12 @@ def hip_batch_generator(pipe, s: Settings):
         out, ctrl, ev, src, subs = handle
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            for t in (out, ctrl, src) + tuple(subs or ()):
+            for t in (out, src) + ((ctrl,) if ctrl is not None else ()) + tuple(subs or ()):
                 t.record_stream(side)
-            o, c, sr = out.cpu(), ctrl.cpu(), src.cpu()
+            o, sr = out.cpu(), src.cpu()
+            c = ctrl.cpu() if ctrl is not None else None
             sb = [t.cpu().numpy() for t in subs] if subs is not None else None
-        return o.numpy(), c.numpy(), sr.numpy(), sb
+        return o.numpy(), (c.numpy() if c is not None else None), sr.numpy(), sb
 
     def run(batch, noises, sources, subjects=None, category=None):
         return finish(enqueue(batch, noises, sources, subjects, category))
@@ -655,7 +675,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
             stem40 = it.image_stem[:MAX_FILENAME_LENGTH]
             if first_variant[it.index] == it.order:
                 png.submit(sources[k], os.path.join(output_folder, f"{stem40}_source.png"))
-                if it.index < 10:
+                if it.index < 10 and controls is not None:       # :441-442 sits inside `if CONTROLNET:`
                     png.submit(controls[k], f"{output_folder}/{stem40}_control.png")
             if subjects is not None and it.subject_path:     # :453-454 "_subject_{i}.png" (excluded from the JSON by name)
                 png.submit(subjects[k], os.path.join(output_folder, f"{stem40}_subject_{it.i}.png"))

@@ -149,7 +149,8 @@ class PNDMScheduler:
 class UniPCMultistepScheduler:
     """`UniPCMultistepScheduler.from_config(pipe.scheduler.config)` (run_aug/run_aug.py:218-219, `sampler="unipcmultistep"`;
     SURVEY 8f f4): the class defaults on top of the SD-1.5 config -- solver_order 2, "bh2", predict_x0, epsilon prediction,
-    lower_order_final, no thresholding, "leading" spacing with steps_offset 1, final_sigmas_type "zero".  Host-side state
+    lower_order_final, no thresholding, "leading" spacing with steps_offset 1 (or "trailing" when built from the sdxl-turbo
+    scheduler config, :223-226), final_sigmas_type "zero".  Host-side state
     only: every UniPC update (the corrector that revises the previous step with the new model output, then the
     predictor to the next timestep) is a LINEAR combination of the samples and the x0-predictions kept on the device, so
     `plan()` turns a step count into per-step coefficient rows for the fused kernel `saspa_unipc_step`:
@@ -170,8 +171,8 @@ class UniPCMultistepScheduler:
         c = self.config
         if c["beta_schedule"] != "scaled_linear" or c["prediction_type"] != "epsilon" or not c["predict_x0"]:
             raise NotImplementedError("only the SD-1.5 UniPC configuration (epsilon, predict_x0) is implemented")
-        if c["solver_order"] not in (1, 2) or c["solver_type"] not in ("bh1", "bh2") or c["timestep_spacing"] != "leading":
-            raise NotImplementedError("UniPC: solver_order <= 2, bh1 / bh2, leading spacing")
+        if c["solver_order"] not in (1, 2) or c["solver_type"] not in ("bh1", "bh2") or c["timestep_spacing"] not in ("leading", "trailing"):
+            raise NotImplementedError("UniPC: solver_order <= 2, bh1 / bh2, leading / trailing spacing")
         n = c["num_train_timesteps"]
         betas = torch.linspace(c["beta_start"] ** 0.5, c["beta_end"] ** 0.5, n, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
@@ -189,8 +190,13 @@ class UniPCMultistepScheduler:
         c = self.config
         n = c["num_train_timesteps"]
         self.num_inference_steps = num_inference_steps
-        ratio = n // (num_inference_steps + 1)
-        ts = (np.arange(0, num_inference_steps + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + c["steps_offset"]
+        if c["timestep_spacing"] == "leading":
+            ratio = n // (num_inference_steps + 1)
+            ts = (np.arange(0, num_inference_steps + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + c["steps_offset"]
+        else:
+            # "trailing": what UniPCMultistepScheduler.from_config inherits from the sdxl-turbo scheduler config
+            # (run_aug/run_aug.py:223-226 with sampler = "unipcmultistep"); 2 steps -> [999, 499]
+            ts = np.arange(n, 0, -n / num_inference_steps).round().copy().astype(np.int64) - 1
         ac = self.alphas_cumprod.double().numpy()
         sig = np.sqrt((1 - ac) / ac)
         sig = np.interp(ts, np.arange(0, len(sig)), sig)

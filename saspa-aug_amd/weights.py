@@ -419,7 +419,16 @@ def _fill_big(pending, seed):
         gj = torch.Generator().manual_seed(sd_)
         flat[r0:r1] = torch.randn((r1 - r0, flat.shape[1]), generator=gj) * scale
 
-    with cf.ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 4)))) as ex:
+    # one process per GPU each synthesises its own copy (bench.py --gpus N, run_aug with SASPA_GPUS): the ranks of a node
+    # share its cores, so every rank takes its share instead of 16 threads each (8 ranks x 16 threads in a 16-thread
+    # cgroup spent the start-up thrashing); SASPA_SYNTH_THREADS overrides
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 4
+    workers = int(os.environ.get("SASPA_SYNTH_THREADS", "0")) or max(1, min(16, ncpu // local_world))
+    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(draw, jobs, chunksize=1))
 
 

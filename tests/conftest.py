@@ -16,16 +16,50 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The production-size parity tests (BASELINE configs[1] / [2] / [4] and the configs[3] bucket sizes) run FIRST: if a slow box
+# runs the suite into the driver's limit, what is cut off is a kernel-level case, never the evidence for the configurations
+# the benchmark is quoted on.  (Round 2 skipped them on a time budget instead, which made that evidence optional.)
+_FIRST = ("test_production_gpu.py", "test_production_families_gpu.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: 0 if it.fspath.basename in _FIRST else 1)      # stable: the order inside each class is kept
+
+
 @pytest.fixture
 def heavy_budget():
-    """Safety net for the production-size tests (each 1.5-3.5 min, mostly CPU oracle time): the whole `-m gpu` suite takes
-    ~13 min on a fresh box; should a box be so slow that the session has already used SASPA_TEST_BUDGET_S seconds (default
-    1000) when such a test starts, it skips itself with this reason instead of running the suite into a driver timeout.
-    Their measured results are committed under profiles/ (r2_production_*.log)."""
-    used = time.time() - _SESSION_T0
-    limit = float(os.environ.get("SASPA_TEST_BUDGET_S", "1000"))
-    if used > limit:
-        pytest.skip(f"session time budget: {used:.0f} s used > {limit:.0f} s (SASPA_TEST_BUDGET_S)")
+    """Kept as a no-op so that older test signatures still resolve: nothing is skipped on a time budget any more."""
+    return None
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _synth_family_cache():
+    """The full-width SD-1.5 / BLIP state dicts (5.6 - 7.6 GB of fp32, ~7 s each on a thread pool) are synthesised by a
+    dozen tests with the same (config, seed): keep the last two families of that size for the session.  Callers get fresh
+    dicts over the SAME tensors (nothing in the package or the tests writes into a state-dict tensor); the 19 GB SDXL
+    family and the tiny ones are not cached."""
+    import collections
+    import json
+
+    from saspa_aug_amd import weights as W
+    real, cache = W.synth_family, collections.OrderedDict()
+
+    def cached(cfgs, seed=0):
+        wide = cfgs.get("unet", {}).get("block_out", (0,))[0] >= 320
+        if not wide or "text2" in cfgs:
+            return real(cfgs, seed)
+        key = (json.dumps(cfgs, sort_keys=True, default=str), seed)
+        if key not in cache:
+            cache[key] = real(cfgs, seed)
+            while len(cache) > 2:
+                cache.popitem(last=False)
+        cache.move_to_end(key)
+        return {k: dict(v) for k, v in cache[key].items()}
+
+    W.synth_family = cached
+    yield
+    W.synth_family = real
+    cache.clear()
 
 
 @pytest.fixture(scope="session")

@@ -234,3 +234,17 @@ def test_pipeline_fp32_parity_sd15_512(dev):
     d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, 512, 512, 2)
     print(f"fp32 SD-1.5 512x512, 2 steps: max|d|={d01:.2e} u8 diff {du8} PSNR={psnr:.1f}")
     assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)
+
+
+@pytest.mark.parametrize("hh,ww,steps", [(512, 704, 2), (512, 768, 1)])
+def test_pipeline_fp32_parity_sd15_nonsquare(dev, hh, ww, steps):
+    """The sizes BASELINE configs[3] really produces: `resize_image` (all_utils/utils.py:58-79, called at
+    run_aug/run_aug.py:372-374) turns FGVC-Aircraft photographs into 512x704 / 512x768 (smaller side 512, both sides
+    rounded to 64).  Full SD-v1.5 + ControlNet + VAE + CLIP-L widths, fp32 path vs the CPU oracle, atol 1e-3 per pixel.
+    Latents 64x88 / 64x96: 5 632 / 6 144 tokens at level 0, 16x22 / 16x24 and 8x11 / 8x12 pixels at the deep levels
+    (row blocks that are no multiple of the 128 / 256-row tiles)."""
+    cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
+    fam = W.synth_family(cfgs, seed=0)
+    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, hh, ww, steps)
+    print(f"fp32 SD-1.5 {hh}x{ww}, {steps} step(s): max|d|={d01:.2e} u8 diff {du8} PSNR={psnr:.1f}")
+    assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)

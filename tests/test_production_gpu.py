@@ -121,6 +121,28 @@ def test_bf16_graph_batch8_vs_oracle_short_trajectory(dev, prod):
     assert lat_rms < 5.4e-2 and psnr > 35.4, (lat_rel, lat_rms, d01, psnr)
 
 
+def test_bf16_graph_batch8_nonsquare_vs_oracle(dev, prod):
+    """The dominant bucket of BASELINE configs[3] (FGVC-Aircraft resized by all_utils/utils.py:58-79 -> 512x704): batch 8,
+    bf16 + hipGraph, 3 DDIM steps, image 0 against the CPU oracle -- the same comparison as (a) at the size the dispatch
+    heuristics were NOT tuned on (M = 90 112 / 22 528 / 5 632 / 1 408 rows, 5 632-token attention)."""
+    cfgs, fam, pipe = prod["cfgs"], prod["fam"], prod["pipe"]
+    hh, ww, steps = 512, 704, 3
+    ctrls = np.stack([generate_canny_array(synthetic_image(hh, ww, 140 + i), 120, 200) for i in range(B)])
+    lat = torch.randn((B, 4, hh // 8, ww // 8), generator=torch.Generator().manual_seed(2), dtype=torch.float16)
+    out, x, img = pipe.generate_batch(prod["ids"], prod["neg"], ctrls, lat, steps, return_latents=True)
+    assert torch.isfinite(from_nhwc(img, 3)).all()
+    ref_u8, ref_x, ref_img = OP.sd_controlnet_pipeline(fam, cfgs, torch.from_numpy(prod["ids"][:1]), torch.from_numpy(prod["neg"]),
+                                                       ctrls[0], lat[:1].float(), steps, return_latents=True)
+    got_x = from_nhwc(x[:1], 4)
+    lat_rms = ((got_x - ref_x).pow(2).mean().sqrt() / ref_x.pow(2).mean().sqrt()).item()
+    got01, ref01 = _img01(img[:1]), _img01(ref_img, nchw=True)
+    d01, psnr = (got01 - ref01).abs().max().item(), _psnr(got01, ref01)
+    print(f"\n[production 512x704] bf16+graph batch 8 vs oracle, {steps} steps, image 0: latents rms-rel {lat_rms:.3e}; "
+          f"image max|d| {d01:.4f} PSNR {psnr:.1f} dB")
+    # same bounds as (a) (2x the 512x512 measurements): the non-square bucket must be no worse than the tuned size
+    assert lat_rms < 5.4e-2 and psnr > 35.4, (lat_rms, d01, psnr)
+
+
 def test_bf16_vs_fp32_hip_batch8_50_steps(dev, prod, p32):
     """(b) the benchmark trajectory (batch 8, 50 DDIM steps, bf16, graph) against the exact-fp32 HIP path, item by item."""
     cfgs, fam, pipe = prod["cfgs"], prod["fam"], prod["pipe"]

@@ -14,7 +14,7 @@ from saspa_aug_amd import config as CFG
 from saspa_aug_amd import models, ops
 from saspa_aug_amd import run_aug as R
 from saspa_aug_amd import weights as W
-from saspa_aug_amd.pipeline import StableDiffusionControlNetImg2ImgPipeline
+from saspa_aug_amd.pipeline import StableDiffusionControlNetImg2ImgPipeline, StableDiffusionImg2ImgPipeline
 from saspa_aug_amd.synthetic import synthetic_image
 from tests.util import from_nhwc, to_nhwc
 
@@ -118,4 +118,62 @@ def test_img2img_call_form_and_run_aug(dev, tiny, tmp_path):
                   control_image=Image.fromarray(generate_canny_array(np.array(Image.open(it.source_path).convert("RGB")), 120, 200)),
                   strength=0.85, num_inference_steps=4, generator=g, guidance_scale=7.5, negative_prompt=R.NEGATIVE_PROMPT,
                   controlnet_conditioning_scale=0.75).images[0]
+    assert np.array_equal(np.asarray(single), np.array(Image.open(it.output_path)))
+
+
+# ---- ControlNet-free img2img: the Real-Guidance form (CONTROLNET = None, SDEDIT = 1; run_aug/run_aug.py:163-165) ----
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_plain_img2img_pipeline_fp32_parity(dev, tiny, graph, monkeypatch):
+    """StableDiffusionImg2ImgPipeline against its oracle restatement: strength 0.15 of 50 steps keeps 7 (the Real-Guidance
+    operating point, run_aug/run_aug_real_guidance.py:520-523), 0.5 of 10 keeps 5; atol 1e-3 per pixel, <= 1 u8 level."""
+    monkeypatch.setenv("SASPA_GRAPH", graph)
+    cfgs, fam = tiny
+    assert StableDiffusionImg2ImgPipeline.kept_steps(50, 0.15) == (43, 7)
+    nimg, hh, ww = 2, 64, 96
+    ids = torch.from_numpy(np.random.RandomState(1).randint(0, cfgs["text"]["vocab"] - 2, (nimg, 77)))
+    neg = torch.from_numpy(np.random.RandomState(2).randint(0, cfgs["text"]["vocab"] - 2, (1, 77)))
+    srcs = np.stack([synthetic_image(hh, ww, 30 + i) for i in range(nimg)])
+    g = torch.manual_seed(1)
+    e = [torch.randn((1, 4, hh // 8, ww // 8), generator=g) for _ in range(2 * nimg)]
+    e1, e2 = torch.cat(e[0::2]), torch.cat(e[1::2])
+    pipe = StableDiffusionImg2ImgPipeline(fam, cfgs).to(dev, torch.float32)
+    assert pipe.controlnet is None
+    for steps, strength in (((50, 0.15), (10, 0.5)) if graph == "1" else ((10, 0.5),)):
+        refs = [OP.sd_img2img_pipeline(fam, cfgs, ids[i:i + 1], neg, srcs[i], e1[i:i + 1], e2[i:i + 1], steps, strength, return_latents=True)
+                for i in range(nimg)]
+        out, x, img = pipe.generate_batch_img2img(ids.numpy(), neg.numpy(), srcs, e1, e2, steps, strength, return_latents=True)
+        ref_img = torch.cat([r[2] for r in refs])
+        d01 = ((from_nhwc(img, 3) / 2 + 0.5).clamp(0, 1) - (ref_img / 2 + 0.5).clamp(0, 1)).abs().max().item()
+        du8 = int(np.abs(out.cpu().numpy().astype(int) - np.concatenate([r[0] for r in refs]).astype(int)).max())
+        assert d01 < 1e-3 and du8 <= 1, (steps, strength, d01, du8)
+    with pytest.raises(ValueError):          # a control image is refused by the ControlNet-free pipeline
+        StableDiffusionControlNetImg2ImgPipeline.generate_batch_img2img(pipe, ids.numpy(), neg.numpy(), srcs, srcs, e1, e2, 10, 0.5)
+
+
+def test_plain_img2img_call_form_and_run_aug(dev, tiny, tmp_path):
+    """init_pipeline("sd_v1.5", None, 1) -> StableDiffusionImg2ImgPipeline; pass_thorugh_pipe's kwargs (:235-241, :274-276);
+    the batched loop writes under regular/sd_v1.5-SDEdit_strength_s/None/ (:668-692) and no *_control.png (:435-442)."""
+    cfgs, fam = tiny
+    pipe = R.init_pipeline("sd_v1.5", None, 1, cfgs=cfgs, state_dicts=fam)
+    assert isinstance(pipe, StableDiffusionImg2ImgPipeline)
+    pipe = pipe.to("cuda:0", torch.float16)
+    src = Image.fromarray(synthetic_image(64, 128, 4))
+    a = R.pass_thorugh_pipe("sd_v1.5", pipe, "an airplane", src, 1, 0.5, 6, torch.manual_seed(1), 7.5, 0.75, control_image=None)
+    b = pipe(prompt="an airplane", image=src, strength=0.5, num_inference_steps=6, generator=torch.manual_seed(1), guidance_scale=7.5,
+             negative_prompt=R.NEGATIVE_PROMPT).images[0]
+    assert a.size == (128, 64) and np.array_equal(np.asarray(a), np.asarray(b))
+    prompts = tmp_path / "p.txt"
+    prompts.write_text("A white airplane on a runway.\nAn airplane above the clouds.\n")
+    s = R.Settings(DATASET="synthetic", NUM_PER_IMAGE=2, SEED=1, RESOLUTION=64, BATCH_SIZE=3, PROMPTS_FILE=str(prompts), SDEDIT=1,
+                   CONTROLNET=None, SDEDIT_STRENGTH=0.5, NUM_INFERENCE_STEPS=4, SEMANTIC_FILTERING=0, MODEL_CONFIDENCE_BASED_FILTERING=0,
+                   DATASET_KWARGS=dict(root_path=str(tmp_path / "ds/data"), n_images=3, sizes=((64, 64),), seed=3))
+    res = R.main(s, pipe=pipe)
+    assert (res["status"] == 1).all()
+    assert "/aug_data/regular/sd_v1.5-SDEdit_strength_0.5/None/" in res["output_folder"]
+    import pathlib
+    names = [p.name for p in pathlib.Path(res["output_folder"]).glob("*.png")]
+    assert not any(n.endswith("_control.png") for n in names) and sum(n.endswith("_source.png") for n in names) == 3
+    it = res["items"][0]
+    single = pipe(prompt=it.prompt, image=Image.open(it.source_path).convert("RGB"), strength=0.5, num_inference_steps=4,
+                  generator=torch.manual_seed(1), guidance_scale=7.5, negative_prompt=R.NEGATIVE_PROMPT).images[0]
     assert np.array_equal(np.asarray(single), np.array(Image.open(it.output_path)))

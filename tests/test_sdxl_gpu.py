@@ -126,7 +126,7 @@ def test_unet_controlnet_tiny_xl_nonsquare(dev, tiny_xl, dtype):
     assert max(e) < _limits(dtype), e
 
 
-def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg, upcast=True, guidance=0.0, negative=False):
+def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg, upcast=True, guidance=0.0, negative=False, sampler="ddim"):
     from oracle.canny import generate_canny_array
     ids1, ids2 = _ids(cfgs, nimg)
     n1 = n2 = None
@@ -138,8 +138,11 @@ def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg, upcast=True, guid
     tn = (lambda a: None if a is None else torch.from_numpy(a))
     refs = [OP.sdxl_controlnet_pipeline(fam, cfgs, torch.from_numpy(ids1[i:i + 1]), torch.from_numpy(ids2[i:i + 1]), ctrls[i],
                                         lat[i:i + 1], steps, return_latents=True, guidance_scale=guidance, neg_ids1=tn(n1),
-                                        neg_ids2=tn(n2)) for i in range(nimg)]
+                                        neg_ids2=tn(n2), sampler=sampler) for i in range(nimg)]
     pipe = StableDiffusionXLControlNetPipeline(fam, cfgs)
+    if sampler == "unipc":
+        from saspa_aug_amd.scheduler import UniPCMultistepScheduler
+        pipe.scheduler = UniPCMultistepScheduler.from_config(pipe.scheduler.config)
     if upcast:
         pipe.upcast_vae()
     pipe = pipe.to(dev, dtype)
@@ -161,6 +164,26 @@ def test_sdxl_pipeline_fp32_parity_tiny(dev, tiny_xl):
     assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
     d01, du8, ex, _ = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 128, 4, nimg=1)
     assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_sdxl_pipeline_unipc_fp32_parity_tiny(dev, tiny_xl, graph, monkeypatch):
+    """sampler = "unipcmultistep" on sd_xl-turbo (run_aug/run_aug.py:223-226): UniPC built from the pipeline's scheduler
+    config ("trailing" spacing: 2 steps -> t = 999, 499), no CFG (the CFG-free update kernel saspa_unipc_step), and with
+    CFG through the same path; fp32 vs the oracle, graph replay and the Python launch loop."""
+    monkeypatch.setenv("SASPA_GRAPH", graph)
+    from saspa_aug_amd.scheduler import UniPCMultistepScheduler
+    from saspa_aug_amd.scheduler import SDXL_TURBO_SCHEDULER_CONFIG
+    sch = UniPCMultistepScheduler.from_config(SDXL_TURBO_SCHEDULER_CONFIG)
+    assert list(sch.set_timesteps(2)) == [999, 499] and list(sch.set_timesteps(4)) == [999, 749, 499, 249]
+    cfgs, fam = tiny_xl
+    d01, du8, ex, pipe = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 64, 2, nimg=2, sampler="unipc")
+    assert isinstance(pipe.scheduler, UniPCMultistepScheduler)
+    assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
+    d01, du8, ex, _ = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 128, 4, nimg=1, sampler="unipc")
+    assert d01 < 1e-3 and du8 <= 1 and ex < 3e-4, (d01, du8, ex)
+    d01, du8, ex, _ = _pipeline_case(cfgs, fam, dev, torch.float32, 64, 64, 4, nimg=2, guidance=5.0, negative=True, sampler="unipc")
+    assert d01 < 1e-3 and du8 <= 1 and ex < 5e-4, (d01, du8, ex)
 
 
 @pytest.mark.parametrize("negative", [False, True])
@@ -216,6 +239,12 @@ def test_sdxl_call_form_and_init_pipeline(dev, tiny_xl):
     assert a.size == (96, 64) and np.array_equal(np.asarray(a), np.asarray(b))
     c = pipe(generator=torch.manual_seed(1), **dict(kw, guidance_scale=5.0, negative_prompt="blurry")).images[0]
     assert c.size == (96, 64) and not np.array_equal(np.asarray(c), np.asarray(b))      # guidance changes the image
+    # sampler = "unipcmultistep" (run_aug/run_aug.py:223-226): same construction, UniPC from the pipeline's config
+    from saspa_aug_amd.scheduler import UniPCMultistepScheduler
+    pu = R.init_pipeline("sd_xl-turbo", "canny", 0, sampler="unipcmultistep", cfgs=cfgs, state_dicts=fam)
+    assert isinstance(pu.scheduler, UniPCMultistepScheduler) and pu.scheduler.config["timestep_spacing"] == "trailing"
+    d = pu.to("cuda:0", torch.float16)(generator=torch.manual_seed(1), **kw).images[0]
+    assert d.size == (96, 64) and not np.array_equal(np.asarray(d), np.asarray(b))
 
 
 @pytest.fixture(scope="module")

@@ -22,11 +22,14 @@ def _recurrence(plan, x, eps_list):
     return x, m0
 
 
+@pytest.mark.parametrize("spacing", ["leading", "trailing"])
 @pytest.mark.parametrize("steps", [1, 2, 3, 10, 30, 50])
-def test_plan_equals_the_stateful_scheduler(steps):
-    sch = UniPCMultistepScheduler()
+def test_plan_equals_the_stateful_scheduler(steps, spacing):
+    """"trailing" is what UniPCMultistepScheduler.from_config inherits from the sdxl-turbo scheduler config
+    (run_aug/run_aug.py:223-226)."""
+    sch = UniPCMultistepScheduler(timestep_spacing=spacing)
     plan = sch.plan(steps)
-    o = OP.UniPC()
+    o = OP.UniPC(spacing=spacing)
     ts = o.set_timesteps(steps)
     assert [t for t, _ in plan] == ts.tolist() and len(plan) == steps
     g = torch.Generator().manual_seed(steps)

@@ -59,13 +59,12 @@ def _bert_ffn(sd, lp, sfx, x, eps):
     return layer_norm(sd, f"{lp}.output{sfx}.LayerNorm", linear(sd, f"{lp}.output{sfx}.dense", h) + x, eps)
 
 
-def blip2_qformer_forward(sd, cfg, pixel_values, input_ids):
-    """Blip2QFormerModel.forward(image_input, text_input, return_dict=False): proj_layer(sequence_output[:, :nq])."""
-    b, t = input_ids.shape
+def qformer_encoder(sd, cfg, x, image_embeds):
+    """Blip2QFormerModel's embedding LayerNorm + encoder on the concatenated [queries | text] embeddings `x` [B, nq + T, W]
+    with the image tokens as cross-attention memory: self-attention over all tokens, cross-attention for the query part
+    every `cross_freq` layers, separate feed-forward weights for the query part (`*_query`) and the text part.
+    PINNED against transformers.Blip2QFormerModel on the same state dict (tests/test_oracle.py)."""
     nq, eps = cfg["num_query"], cfg["eps"]
-    image_embeds = blip2_vision_forward(sd, cfg, pixel_values)
-    txt = sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][:t][None]
-    x = torch.cat([sd["query_tokens"].expand(b, -1, -1), txt], 1)
     x = layer_norm(sd, "embeddings.LayerNorm", x, eps)
     for i in range(cfg["layers"]):
         lp = f"encoder.layer.{i}"
@@ -76,6 +75,17 @@ def blip2_qformer_forward(sd, cfg, pixel_values, input_ids):
         q = _bert_ffn(sd, lp, "_query", q, eps)
         tx = _bert_ffn(sd, lp, "", tx, eps)
         x = torch.cat([q, tx], 1)
+    return x
+
+
+def blip2_qformer_forward(sd, cfg, pixel_values, input_ids):
+    """Blip2QFormerModel.forward(image_input, text_input, return_dict=False): proj_layer(sequence_output[:, :nq])."""
+    b, t = input_ids.shape
+    nq, eps = cfg["num_query"], cfg["eps"]
+    image_embeds = blip2_vision_forward(sd, cfg, pixel_values)
+    txt = sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][:t][None]
+    x = torch.cat([sd["query_tokens"].expand(b, -1, -1), txt], 1)
+    x = qformer_encoder(sd, cfg, x, image_embeds)
     x_in = x[:, :nq]
     h = layer_norm(sd, "proj_layer.LayerNorm", x_in, eps)
     h = linear(sd, "proj_layer.dense1", h)

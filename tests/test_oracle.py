@@ -217,3 +217,54 @@ def test_clip_preprocess_and_safety_checker_oracle():
     assert flags == [False, False] and cs.shape == (2, 17) and ss.shape == (2, 3)
     n = sum(torch.Size(s).numel() for _, s, _ in W.SPECS["safety"](CFG.SAFETY_CHECKER))
     assert n == 303981588          # CLIPVisionModel ViT-L/14 303 179 776 + projection 786 432 + concept tables 15 380
+
+
+def test_clip_vision_tower_matches_transformers():
+    """The safety checker's image tower (oracle/image_ops.clip_vision_forward, CLIP ViT: class token, "pre_layrnorm" sic,
+    quick-GELU, post_layernorm on the class token) against an INDEPENDENT implementation on the same weights:
+    transformers.CLIPVisionModelWithProjection; its `image_embeds` = visual_projection(pooled) is what the checker compares
+    with the concept embeddings."""
+    tr = pytest.importorskip("transformers")
+    from oracle import image_ops as IO
+    cfg = dict(width=64, layers=3, heads=4, mlp=128, patch=14, image_size=56)
+    hf = tr.CLIPVisionModelWithProjection(tr.CLIPVisionConfig(
+        hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14,
+        projection_dim=32, hidden_act="quick_gelu", layer_norm_eps=1e-5)).eval()
+    g = torch.Generator().manual_seed(3)
+    sd = {k: torch.randn(v.shape, generator=g) * (0.2 if v.dim() > 1 else 0.5) + (1.0 if k.endswith("norm.weight") or "layer_norm" in k and k.endswith("weight") else 0.0)
+          for k, v in hf.state_dict().items() if "position_ids" not in k}
+    missing = hf.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if "position_ids" not in k] and not missing.unexpected_keys
+    px = torch.randn(2, 3, 56, 56, generator=g)
+    with torch.no_grad():
+        ref = hf(pixel_values=px)
+        pooled = IO.clip_vision_forward(sd, cfg, px, pfx="vision_model")
+        emb = torch.nn.functional.linear(pooled, sd["visual_projection.weight"])
+    assert (ref.image_embeds - emb).abs().max().item() < 2e-4 * max(1.0, ref.image_embeds.abs().max().item())
+
+
+def test_qformer_encoder_matches_transformers():
+    """The BLIP-Diffusion Q-Former's encoder (oracle/blip_models.qformer_encoder: joint self-attention of the 16 queries and
+    the category tokens, cross-attention to the image tokens every other layer, separate query / text feed-forward weights)
+    against transformers.Blip2QFormerModel with text input on the same state dict.  (The vision tower in front of it and the
+    projection head behind it are diffusers-specific modules with no counterpart in transformers: those stay unpinned.)"""
+    tr = pytest.importorskip("transformers")
+    from oracle import blip_models as OB
+    nq, nt, w, vis = 6, 5, 64, 48
+    cfg = dict(num_query=nq, eps=1e-12, layers=4, heads=4, cross_freq=2)
+    hf = tr.Blip2QFormerModel(tr.Blip2QFormerConfig(
+        vocab_size=100, hidden_size=w, num_hidden_layers=4, num_attention_heads=4, intermediate_size=128,
+        cross_attention_frequency=2, encoder_hidden_size=vis, max_position_embeddings=32, use_qformer_text_input=True,
+        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).eval()
+    g = torch.Generator().manual_seed(5)
+    hsd = {k: torch.randn(v.shape, generator=g) * (0.15 if v.dim() > 1 else 0.3) + (1.0 if "LayerNorm.weight" in k or k == "layernorm.weight" else 0.0)
+           for k, v in hf.state_dict().items()}
+    hf.load_state_dict(hsd)
+    sd = {("embeddings.LayerNorm." + k.split(".", 1)[1] if k.startswith("layernorm.") else k): v for k, v in hsd.items()}
+    x = torch.randn(2, nq + nt, w, generator=g)
+    img = torch.randn(2, 9, vis, generator=g)
+    with torch.no_grad():
+        ref = hf(query_embeds=x, query_length=nq, encoder_hidden_states=img).last_hidden_state
+        got = OB.qformer_encoder(sd, cfg, x, img)
+    assert ref.shape == got.shape
+    assert (ref - got).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

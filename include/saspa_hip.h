@@ -115,6 +115,17 @@ typedef struct SaspaGemmParams {
    * so a workgroup re-reads the same input rows back to back (L2 hits) instead of once per pass over all channels.
    * Requires c0 (and c1, if used) to be multiples of the K-tile; SASPA_ERANGE otherwise. */
   int korder;
+  /* GroupNorm statistics out of the epilogue (ABI 12; removes the consumer's statistics pass, saspa_groupnorm_stats).
+   * gn_stats != NULL: besides `out`, the launch leaves, for every block rb of 128 consecutive output rows and every unit u of
+   * gn_unit consecutive output channels, gn_stats[(rb * (N / gn_unit) + u) * 2 + {0, 1}] = (sum, sum of squares) of the
+   * STORED values (after bias / row vector / activation / residual, as rounded to the output dtype) over the block's rows < M.
+   * A unit is the finest channel granule every consuming GroupNorm's groups are made of (block_out[0] / groups = 10 for
+   * SD-1.5 / SDXL), so one buffer serves a plain consumer, a consumer over a channel concat and both consumers of a skip
+   * tensor (SaspaGroupNormParams.stats0 / stats1).  bf16 only, N % 8 == 0, N % gn_unit == 0, gn_unit even and <= 16, every
+   * tile's first column a multiple of gn_unit (the library picks 160 / 320-column tiles), no fused GEGLU, unbatched;
+   * SASPA_ERANGE otherwise.  Deterministic (fixed summation order; no atomics). */
+  float* gn_stats;
+  int gn_unit;
 } SaspaGemmParams;
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 /* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):
@@ -172,6 +183,11 @@ typedef struct SaspaGroupNormParams {
   float* scale_shift;    /* unused since ABI 10 (the apply pass derives scale / shift itself); may be NULL */
   int act;
   void* y; int ldy;      /* apply output [batch*hw][C] */
+  /* ABI 12: statistics left by the producers' epilogues (SaspaGemmParams.gn_stats) instead of a saspa_groupnorm_stats
+   * launch: stats0 belongs to x0, stats1 to x1 (NULL without x1); each is [batch * hw / 128][c_i / unit][2] floats.
+   * Needs hw % 128 == 0, c0 % unit == 0 and (C / groups) % unit == 0; `partial` / `nsplit` are then unused. */
+  const float* stats0; const float* stats1;
+  int unit;
 } SaspaGroupNormParams;
 int saspa_groupnorm_stats(const SaspaGroupNormParams* p, void* stream);
 int saspa_groupnorm_apply(const SaspaGroupNormParams* p, void* stream);

@@ -22,7 +22,7 @@ class GemmParams(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int), ("nb1", C.c_int), ("nb2", C.c_int),
         ("sa1", C.c_longlong), ("sa2", C.c_longlong), ("sw1", C.c_longlong), ("sw2", C.c_longlong),
         ("so1", C.c_longlong), ("so2", C.c_longlong), ("ksplit", C.c_int), ("workspace", C.c_void_p),
-        ("variant", C.c_int), ("korder", C.c_int),
+        ("variant", C.c_int), ("korder", C.c_int), ("gn_stats", C.c_void_p), ("gn_unit", C.c_int),
     ]
 
 
@@ -43,6 +43,7 @@ class GroupNormParams(C.Structure):
         ("ldx0", C.c_int), ("ldx1", C.c_int), ("batch", C.c_int), ("hw", C.c_int), ("groups", C.c_int),
         ("eps", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
         ("nsplit", C.c_int), ("scale_shift", C.c_void_p), ("act", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int),
+        ("stats0", C.c_void_p), ("stats1", C.c_void_p), ("unit", C.c_int),
     ]
 
 

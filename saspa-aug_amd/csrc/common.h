@@ -154,4 +154,37 @@ __device__ __forceinline__ u32x4 buf_load(rsrc_t r, unsigned voff, unsigned soff
 }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// GroupNorm statistics of one block of <= 128 finished output rows held in LDS as bf16 (`ct`: rows of `cp` elements, the
+// STORED values): per unit of `unit` consecutive channels (nunits of them, nunits divides NT) the sum and the sum of squares
+// over rows [0, nrows) -> dst[nunits][2].  Fixed summation order (thread (unit, row group) over its interleaved rows, then
+// one thread per value over the row groups): deterministic.  scratch: 2 * NT floats of LDS; ends with the caller's barrier.
+template <int NT>
+__device__ __forceinline__ void gn_tile_stats(const bf16_t* ct, const int cp, const int nrows, const int nunits, const int unit,
+                                              float* scratch, float* dst) {
+  const int tid = threadIdx.x;
+  const int rgs = NT / nunits;
+  const int u = tid % nunits, rg = tid / nunits;
+  float sm = 0.f, sq = 0.f;
+  if (rg < rgs) {
+    for (int r = rg; r < nrows; r += rgs) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(ct + r * cp + u * unit);
+      for (int j = 0; j < unit; j += 2) {
+        const uint32_t w = src[j >> 1];
+        const float a = __builtin_bit_cast(float, w << 16), b = __builtin_bit_cast(float, w & 0xffff0000u);
+        sm += a + b;
+        sq += a * a + b * b;
+      }
+    }
+    scratch[(rg * nunits + u) * 2] = sm;
+    scratch[(rg * nunits + u) * 2 + 1] = sq;
+  }
+  __syncthreads();
+  if (tid < nunits * 2) {
+    const int uu = tid >> 1, k = tid & 1;
+    float a = 0.f;
+    for (int g = 0; g < rgs; ++g) a += scratch[(g * nunits + uu) * 2 + k];
+    dst[uu * 2 + k] = a;
+  }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

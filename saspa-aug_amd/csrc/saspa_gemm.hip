@@ -193,8 +193,25 @@ __device__ __forceinline__ void gemm_epilogue(const SaspaGemmParams& p, f32x4 (&
             for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
           }
           c4 = __builtin_bit_cast(u32x4, pack8(a));
+          if (p.gn_stats) *reinterpret_cast<u32x4*>(ct + row * CP + ch * 8) = c4;   // the statistics read the STORED values
         }
         *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
+      }
+      if constexpr (sizeof(T) == 2) if (p.gn_stats) {
+        // GroupNorm statistics of this tile's row block (SaspaGemmParams.gn_stats): BM = 128 rows = one block
+        static_assert(BM == 128 || BM == 256 || BM <= 64, "row blocks of the statistics are 128 rows");
+        __syncthreads();
+        const int nunits = BN / p.gn_unit;
+        float* scratch = reinterpret_cast<float*>(ct + BM * CP);
+#pragma unroll
+        for (int hb = 0; hb < (BM + 127) / 128; ++hb) {
+          const int r0 = hb * 128;
+          const int nrows = min(128, min(BM, p.M - cbm * BM) - r0);
+          if (nrows > 0)
+            gn_tile_stats<NT>(reinterpret_cast<const bf16_t*>(ct) + r0 * CP, CP, nrows, nunits, p.gn_unit, scratch,
+                              p.gn_stats + (((long long)(cbm * BM + r0) / 128) * (p.N / p.gn_unit) + (cbn * BN) / p.gn_unit) * 2);
+          if (hb + 1 < (BM + 127) / 128) __syncthreads();
+        }
       }
     } else {
       // tile columns [0, BN/2) are values, [BN/2, BN) the matching gates (weights packed so)
@@ -894,6 +911,53 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SaspaGemmParam
   }
 }
 
+// split-K reduce + epilogue + GroupNorm statistics (SaspaGemmParams.gn_stats): one workgroup per (128-row block, 160-column
+// slab); the finished bf16 slab is staged in LDS like a GEMM tile and gn_tile_stats reads it.  bf16 only.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const SaspaGemmParams p, int ksplit) {
+  constexpr int BR = 128, BC = 160, CP = BC + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t ct[BR * CP + 4 * 256];
+  const int tid = threadIdx.x;
+  const int rb = blockIdx.x, cs = blockIdx.y;
+  const long long slab = (long long)p.M * p.N;
+  const int hw = p.hout * p.wout;
+  bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
+  const int nrows = min(BR, p.M - rb * BR);
+  for (int q = tid; q < nrows * (BC / 4); q += 256) {
+    const int row = q / (BC / 4), c4 = q - row * (BC / 4);
+    const int m = rb * BR + row, n = cs * BC + c4 * 4;
+    float4 a = *reinterpret_cast<const float4*>(p.workspace + (long long)m * p.N + n);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(p.workspace + s * slab + (long long)m * p.N + n);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (p.rowvec) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)(m / hw) * p.ldrv + n);
+      v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = act_pre(p.act, v[r] * p.alpha);
+    if (res) {
+      float rr[4];
+      Elem<bf16_t>::load4(res + (long long)m * p.ldr + n, rr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += rr[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = act_post(p.act, v[r]);
+    Elem<bf16_t>::store4(out + (long long)m * p.ldo + n, v);
+    Elem<bf16_t>::store4(ct + row * CP + c4 * 4, v);
+  }
+  __syncthreads();
+  gn_tile_stats<256>(ct, CP, nrows, BC / p.gn_unit, p.gn_unit, reinterpret_cast<float*>(ct + BR * CP),
+                     p.gn_stats + ((long long)rb * (p.N / p.gn_unit) + (cs * BC) / p.gn_unit) * 2);
+}
+
 template <typename T, int WM, int WN, int NWM = 2, int NWN = 2>
 int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
@@ -949,6 +1013,26 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const long long nb = (long long)p.nb1 * p.nb2;
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
   const bool n160 = (p.N % 160) == 0;
+  if (p.gn_stats) {
+    // statistics need the LDS-staged bf16 epilogue on 160 / 320-column tiles of 128 / 256 rows (saspa_gemm checked the
+    // shape): the 8-wave kernel where AUTO would take it, the 4-wave 128x160 tiles otherwise -- never the wave-specialised
+    // kernel (its epilogue waves have no statistics pass) or the 64x64 tiles
+    if constexpr (sizeof(T) == 2) {
+      if (p.variant == SASPA_GEMM_WS) return SASPA_ERANGE;
+      static const int pp_mode_g = getenv("SASPA_GEMM_PP") ? atoi(getenv("SASPA_GEMM_PP")) : 1;
+      const bool can = nb == 1 && (p.N % 320) == 0 && saspa_gemm_pp_eligible(p);
+      if (p.variant == SASPA_GEMM_WIDE) return can ? saspa_gemm_pp_launch(p, s, ksplit, 5) : SASPA_ERANGE;
+      if (can && pp_mode_g != 0 && p.variant == SASPA_GEMM_AUTO && p.K >= 960) {
+        const long long t = (long long)((p.M + 255) / 256) * (p.N / 320);
+        if (t >= 192) return saspa_gemm_pp_launch(p, s, 1, 5);
+        static const bool wide_ks_g = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);
+        if (wide_ks_g && ksplit > 1 && p.K >= 4096 && t >= 24 && t * ksplit >= 128) return saspa_gemm_pp_launch(p, s, ksplit, 5);
+      }
+      return launch<T, 4, 5>(p, s, ksplit);
+    } else {
+      return SASPA_ERANGE;
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if (p.variant == SASPA_GEMM_WS) return saspa_gemm_ws_launch(p, s);
   } else {
@@ -1042,7 +1126,7 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
     static const int ws_max = getenv("SASPA_GEMM_WS_MAXTILES") ? atoi(getenv("SASPA_GEMM_WS_MAXTILES")) : 512;
     const int bn_t = (p.N % 160 == 0) ? 160 : 128;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + bn_t - 1) / bn_t);
-    if (ws_on && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 && t128 >= 256 && t128 < ws_max &&
+    if (ws_on && !p.gn_stats && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 && t128 >= 256 && t128 < ws_max &&
         saspa_gemm_ws_eligible(p))
       return 1;
   }
@@ -1090,6 +1174,11 @@ int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles
 }
 
 int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
+  if (p.gn_stats) {        // saspa_gemm checked: bf16, N % 160 == 0, 160 % gn_unit == 0
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 127) / 128, p.N / 160), dim3(256), 0, s, p, ksplit);
+    SASPA_CHECK_LAUNCH();
+    return 0;
+  }
   long long blocks = ((long long)p.M * (p.N / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (p.dtype == SASPA_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
@@ -1156,6 +1245,12 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     return SASPA_EINVAL;
   }
   if (p.ksplit > 1 && p.workspace && !aligned16(p.workspace)) return SASPA_EALIGN;
+  if (p.gn_stats) {
+    // epilogue GroupNorm statistics (ABI 12): bf16, whole 160-column tiles whose first column is a multiple of the unit
+    if (p.dtype != SASPA_BF16 || p.act == SASPA_ACT_GEGLU || (long long)p.nb1 * p.nb2 != 1) return SASPA_ERANGE;
+    if (p.gn_unit < 2 || p.gn_unit > 16 || (p.gn_unit & 1) || (160 % p.gn_unit) != 0 || (p.N % 160) != 0) return SASPA_ERANGE;
+    if ((p.ldo % 8) != 0 || (p.residual && (p.ldr % 8) != 0)) return SASPA_ERANGE;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.dtype == SASPA_BF16) return dispatch<bf16_t>(p, s);
   if (p.dtype == SASPA_F32X3) return dispatch<f32x3_t>(p, s);

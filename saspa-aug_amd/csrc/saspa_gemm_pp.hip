@@ -661,8 +661,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
               for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
             }
             c4 = __builtin_bit_cast(u32x4, pack8(a));
+            if (p.gn_stats) *reinterpret_cast<u32x4*>(ct + row * CP + ch * 8) = c4;   // the statistics read the STORED values
           }
           *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
+        }
+        if (p.gn_stats) {
+          // GroupNorm statistics of this half tile = one 128-row block (SaspaGemmParams.gn_stats)
+          __syncthreads();
+          const int nrows = min(128, p.M - (cbm * BM + h * 128));
+          if (nrows > 0)
+            gn_tile_stats<512>(ct, CP, nrows, BN / p.gn_unit, p.gn_unit, reinterpret_cast<float*>(ct + 128 * CP),
+                               p.gn_stats + ((long long)(cbm * 2 + h) * (p.N / p.gn_unit) + (cbn * BN) / p.gn_unit) * 2);
         }
         __syncthreads();
       }

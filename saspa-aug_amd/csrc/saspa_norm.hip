@@ -121,7 +121,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
     for (int g0 = 0; g0 < p.groups; g0 += 32) {
       const int g = g0 + (tid >> 3);
       double sm = 0.0, sq = 0.0;
-      if (g < p.groups) {
+      if (g < p.groups && p.stats0) {
+        // statistics left by the producers' epilogues (SaspaGemmParams.gn_stats): per (128-row block, unit of `unit` channels)
+        // sums of each source; group g = the units of its channel range in source 0 and / or source 1, over the hw / 128 row
+        // blocks of image b.  Same 8-loads-in-flight shape and fp64 combine as the partial-sum path below.
+        const int nblk = p.hw >> 7;
+        const int glo = g * cpg, ghi = glo + cpg;
+        for (int src = 0; src < 2; ++src) {
+          const float* st = src ? p.stats1 : p.stats0;
+          const int cs = src ? p.c1 : p.c0, off = src ? p.c0 : 0;
+          if (!st || cs == 0) continue;
+          const int lo = max(glo, off) - off, hi = min(ghi, off + cs) - off;
+          if (hi <= lo) continue;
+          const int u0 = lo / p.unit, nu = (hi - lo) / p.unit, upr = cs / p.unit;
+          const int total = nu * nblk;
+          for (int e0 = sub; e0 < total; e0 += 64) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = e0 + 8 * u;
+              v[u] = make_float2(0.f, 0.f);
+              if (e < total) {
+                const int blk = e / nu, uu = e - blk * nu;
+                v[u] = *reinterpret_cast<const float2*>(st + (((long long)b * nblk + blk) * upr + u0 + uu) * 2);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              sm += (double)v[u].x;
+              sq += (double)v[u].y;
+            }
+          }
+        }
+      } else if (g < p.groups) {
         // 8 loads in flight per thread and round (64 partial sums per group and round): one L2 round trip for the usual
         // nsplit * slabs <= 64, instead of one per element
         for (int i0 = sub; i0 < nparts; i0 += 64) {
@@ -315,15 +347,25 @@ void launch_layernorm(hipStream_t s, const T* x, int ldx, T* y, int ldy, long lo
 }
 
 int check_gn(const SaspaGroupNormParams& p) {
-  if (!p.x0 || !p.gamma || !p.beta || !p.partial) return SASPA_EINVAL;
-  if (p.batch <= 0 || p.hw <= 0 || p.groups <= 0 || p.nsplit <= 0 || p.c0 <= 0 || p.c1 < 0) return SASPA_EINVAL;
+  if (!p.x0 || !p.gamma || !p.beta || (!p.partial && !p.stats0)) return SASPA_EINVAL;
+  if (p.stats0) {
+    // epilogue statistics (ABI 12): whole 128-row blocks per image, groups and sources made of whole units
+    const int C_ = p.c0 + p.c1;
+    if (p.unit <= 0 || p.groups <= 0 || C_ % p.groups) return SASPA_ERANGE;
+    if ((p.hw & 127) || p.c0 % p.unit || p.c1 % p.unit || (C_ / p.groups) % p.unit) return SASPA_ERANGE;
+    if (p.c1 > 0 && !p.stats1) return SASPA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(p.stats0) & 7u) || (p.stats1 && (reinterpret_cast<uintptr_t>(p.stats1) & 7u))) return SASPA_EALIGN;
+  }
+  if (p.batch <= 0 || p.hw <= 0 || p.groups <= 0 || (p.nsplit <= 0 && !p.stats0) || p.c0 <= 0 || p.c1 < 0) return SASPA_EINVAL;
   if (p.c1 > 0 && !p.x1) return SASPA_EINVAL;
   if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32) return SASPA_EINVAL;
   const int C = p.c0 + p.c1;
   if (p.c0 % 8 || p.c1 % 8 || p.ldx0 % 8 || (p.c1 > 0 && p.ldx1 % 8)) return SASPA_EALIGN;
   if (C % p.groups || p.groups > 256) return SASPA_ERANGE;
   if (!aligned16(p.x0) || (p.x1 && !aligned16(p.x1)) || (reinterpret_cast<uintptr_t>(p.partial) & 7u)) return SASPA_EALIGN;
-  if (p.nsplit > p.hw || p.batch > 65535) return SASPA_ERANGE;
+  if (p.batch > 65535) return SASPA_ERANGE;
+  if (p.stats0) return 0;
+  if (p.nsplit > p.hw) return SASPA_ERANGE;
   // the workspace contract stays batch * nsplit * C * 2 floats; the per-group sums need slabs * groups <= C of it
   if ((long long)gn_geometry(C / 8).slabs * p.groups > C) return SASPA_ERANGE;
   return 0;
@@ -334,6 +376,7 @@ int check_gn(const SaspaGroupNormParams& p) {
 extern "C" int saspa_groupnorm_stats(const SaspaGroupNormParams* pp, void* stream) {
   if (!pp) return SASPA_EINVAL;
   const SaspaGroupNormParams& p = *pp;
+  if (p.stats0 || !p.partial) return SASPA_EINVAL;     // with epilogue statistics there is no statistics pass to launch
   if (int e = check_gn(p)) return e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const GnGeom ge = gn_geometry((p.c0 + p.c1) / 8);

@@ -152,6 +152,9 @@ class _Net:
         self.pk = _Packed(sd, dev, dtype)
         self.p = self.pk.p
         self.temb_tables = {}
+        # GroupNorm statistics out of the producers' epilogues (ops.conv(..., gn_unit=...)): every GroupNorm of the network
+        # has groups of a multiple of block_out[0] / groups channels (10 for SD-1.5 / SDXL), also across a skip concat
+        self.gn_unit = cfg["block_out"][0] // cfg["groups"] if dtype == torch.bfloat16 else None
 
     # ---- packing helpers ----
     def _pack_resnet(self, pfx, split=None):
@@ -302,14 +305,14 @@ class _Net:
         if pfx in self.temb_tables:
             rv = self.temb_cur_views[pfx] if step is None else self.temb_tables[pfx][step]
         h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
-        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv)
+        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv, gn_unit=self.gn_unit)
         h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU)
         if pfx + ".conv_shortcut.w" in p:
             sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"], x2=x2)
         else:
             assert x2 is None
             sc = x
-        return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc)
+        return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc, gn_unit=self.gn_unit)
 
     def _quantize_block(self, t):
         """e4m3 copies (per-output-channel scales) of the two projections that read a LayerNorm's output; the GEGLU
@@ -364,12 +367,12 @@ class _Net:
             else:
                 ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
             h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
-        return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x)
+        return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x, gn_unit=self.gn_unit)
 
     def encode(self, sample, step, conv_in_residual=None):
         """conv_in + down blocks + mid block.  Returns (mid, [skips])."""
         cfg, p = self.cfg, self.p
-        s = ops.conv(sample, p["conv_in.w"], p["conv_in.b"], kh=3, kw=3, pad=1, residual=conv_in_residual)
+        s = ops.conv(sample, p["conv_in.w"], p["conv_in.b"], kh=3, kw=3, pad=1, residual=conv_in_residual, gn_unit=self.gn_unit)
         skips = [s]
         n_lvl = len(cfg["block_out"])
         for i in range(n_lvl):
@@ -380,7 +383,7 @@ class _Net:
                 skips.append(s)
             if i != n_lvl - 1:
                 d = f"down_blocks.{i}.downsamplers.0.conv"
-                s = ops.conv(s, p[d + ".w"], p[d + ".b"], kh=3, kw=3, stride=2, pad=1)
+                s = ops.conv(s, p[d + ".w"], p[d + ".b"], kh=3, kw=3, stride=2, pad=1, gn_unit=self.gn_unit)
                 skips.append(s)
         s = self.resnet("mid_block.resnets.0", s, step, 1e-5)
         s = self.transformer("mid_block.attentions.0", s)
@@ -432,7 +435,7 @@ class UNet(_Net):
                     s = self.transformer(f"up_blocks.{i}.attentions.{j}", s)
             if i != n_lvl - 1:
                 u = f"up_blocks.{i}.upsamplers.0.conv"
-                s = ops.conv(s, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True)
+                s = ops.conv(s, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True, gn_unit=self.gn_unit)
         s = ops.groupnorm(s, p["conv_norm_out.g"], p["conv_norm_out.b"], cfg["groups"], 1e-5, SILU)
         return ops.conv(s, p["conv_out.w"], p["conv_out.b"], kh=3, kw=3, pad=1, out=out)
 
@@ -488,8 +491,9 @@ class ControlNet(_Net):
         for i, f in enumerate(feats):
             r = None if unet_skips is None else unet_skips[i]
             outs.append(ops.conv(f, p[f"controlnet_down_blocks.{i}.w"], p[f"controlnet_down_blocks.{i}.b"], alpha=scale,
-                                 residual=r))
-        m = ops.conv(mid, p["controlnet_mid_block.w"], p["controlnet_mid_block.b"], alpha=scale, residual=unet_mid)
+                                 residual=r, gn_unit=self.gn_unit))
+        m = ops.conv(mid, p["controlnet_mid_block.w"], p["controlnet_mid_block.b"], alpha=scale, residual=unet_mid,
+                     gn_unit=self.gn_unit)
         return outs, m
 
 

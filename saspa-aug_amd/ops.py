@@ -129,12 +129,33 @@ def _set_splitk(p, m, n, k, t, force=None):
     return None
 
 
+def gn_fusion_enabled():
+    """SASPA_GN_FUSE=0: every GroupNorm runs its own statistics pass (A/B knob for the epilogue statistics)."""
+    return os.environ.get("SASPA_GN_FUSE", "1") != "0"
+
+
+def _gn_stats_for(p, out, gn_unit, b, hw, n):
+    """Epilogue GroupNorm statistics (SaspaGemmParams.gn_stats): allocate the [rows / 128, N / unit, 2] fp32 buffer, hang it
+    on the output tensor (`saspa_gn` = (stats, unit): `groupnorm` picks it up and skips its statistics pass) -- when the
+    shape allows it: bf16, whole 128-row blocks per image, whole 160-column tiles, dense output rows."""
+    if not gn_unit or not gn_fusion_enabled() or out.dtype != torch.bfloat16:
+        return None
+    if hw % 128 or n % 160 or 160 % gn_unit or gn_unit % 2 or gn_unit > 16 or out.shape[-1] != n or p.ldo % 8 or (p.residual and p.ldr % 8):
+        return None
+    stats = torch.empty((b * hw // 128, n // gn_unit, 2), device=out.device, dtype=torch.float32)
+    p.gn_stats, p.gn_unit = _ptr(stats), int(gn_unit)
+    out.saspa_gn = (stats, int(gn_unit))
+    return stats
+
+
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
-         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None, out_hw=None):
+         residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None, out_hw=None,
+         gn_unit=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
     (pad channels zero).  ``korder``: K order the weights were packed in (default: the tensor's
-    ``saspa_korder`` attribute set by the packer, else tap-major)."""
+    ``saspa_korder`` attribute set by the packer, else tap-major).  ``gn_unit``: the output feeds a GroupNorm whose
+    groups are multiples of this many channels -> the epilogue leaves its statistics (`_gn_stats_for`)."""
     _check_dev(x, w, bias, x2, rowvec, residual, out)
     lib = _lib.load()
     b, h, wd, c0 = x.shape
@@ -184,6 +205,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
     p.korder = int(getattr(w, "saspa_korder", 0)) if korder is None else int(korder)
+    _gs = _gn_stats_for(p, out, gn_unit, b, ho * wo, n)  # noqa: F841   (set BEFORE the split-K heuristic looks at p)
     _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
             (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
@@ -311,6 +333,24 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
         raise ValueError("GroupNorm output does not match the input geometry")
     if out is None:
         out = torch.empty((b, h, w, ctot), device=x.device, dtype=x.dtype)
+    # statistics left by the producers' epilogues (conv(..., gn_unit=...)): no statistics pass
+    g0, g1 = getattr(x, "saspa_gn", None), (getattr(x2, "saspa_gn", None) if x2 is not None else None)
+    fused = (g0 is not None and (x2 is None or g1 is not None) and gn_fusion_enabled() and (h * w) % 128 == 0
+             and (x2 is None or g1[1] == g0[1]) and c0 % g0[1] == 0 and c1 % g0[1] == 0 and (ctot // groups) % g0[1] == 0
+             and g0[0].shape[1] * g0[1] == c0 and (x2 is None or g1[0].shape[1] * g1[1] == c1))
+    if fused:
+        p = _lib.GroupNormParams()
+        p.dtype = _dt(x)
+        p.x0, p.x1, p.c0, p.c1 = _ptr(x), _ptr(x2), c0, c1
+        p.ldx0 = _pitch4(x)
+        p.ldx1 = 0 if x2 is None else _pitch4(x2)
+        p.batch, p.hw, p.groups, p.eps = b, h * w, groups, float(eps)
+        p.gamma, p.beta = _ptr(gamma), _ptr(beta)
+        p.partial, p.nsplit, p.scale_shift = None, 0, None
+        p.act, p.y, p.ldy = int(act), _ptr(out), _pitch4(out)
+        p.stats0, p.stats1, p.unit = _ptr(g0[0]), (_ptr(g1[0]) if g1 is not None else None), g0[1]
+        _lib.check(lib.saspa_groupnorm_apply(C.byref(p), _stream()), "saspa_groupnorm_apply(epilogue statistics)")
+        return out
     nsplit = _gn_nsplit(b, h * w, ctot // 8)
     partial = torch.empty((b * nsplit * ctot * 2,), device=x.device, dtype=torch.float32)
     p = _lib.GroupNormParams()

@@ -12,8 +12,25 @@ if ROOT not in sys.path:
 _SESSION_T0 = time.time()
 
 
+def _effective_cpus():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU boxes expose 256 logical
+    CPUs behind a 16-core cgroup quota; torch then starts 128 intra-op threads and the CPU oracle runs 5-25x SLOWER than
+    with 16 (tools/cpu_threads_probe.py: full-width 256x256 evaluation 10.2 s vs 2.1 s, the tiny pipeline 7.8 s vs 0.3 s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(_effective_cpus())      # the oracle's thread count = the cores the box really grants
 
 
 # The production-size parity tests (BASELINE configs[1] / [2] / [4] and the configs[3] bucket sizes) run FIRST: if a slow box

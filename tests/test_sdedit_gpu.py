@@ -129,7 +129,7 @@ def test_plain_img2img_pipeline_fp32_parity(dev, tiny, graph, monkeypatch):
     monkeypatch.setenv("SASPA_GRAPH", graph)
     cfgs, fam = tiny
     assert StableDiffusionImg2ImgPipeline.kept_steps(50, 0.15) == (43, 7)
-    nimg, hh, ww = 2, 64, 96
+    nimg, hh, ww = 2, 64, 128
     ids = torch.from_numpy(np.random.RandomState(1).randint(0, cfgs["text"]["vocab"] - 2, (nimg, 77)))
     neg = torch.from_numpy(np.random.RandomState(2).randint(0, cfgs["text"]["vocab"] - 2, (1, 77)))
     srcs = np.stack([synthetic_image(hh, ww, 30 + i) for i in range(nimg)])

@@ -121,7 +121,7 @@ typedef struct SaspaGemmParams {
    * STORED values (after bias / row vector / activation / residual, as rounded to the output dtype) over the block's rows < M.
    * A unit is the finest channel granule every consuming GroupNorm's groups are made of (block_out[0] / groups = 10 for
    * SD-1.5 / SDXL), so one buffer serves a plain consumer, a consumer over a channel concat and both consumers of a skip
-   * tensor (SaspaGroupNormParams.stats0 / stats1).  bf16 only, N % 8 == 0, N % gn_unit == 0, gn_unit even and <= 16, every
+   * tensor (SaspaGroupNormParams.stats0 / stats1).  bf16 only, N % 160 == 0, 80 % gn_unit == 0, gn_unit even and <= 16, every
    * tile's first column a multiple of gn_unit (the library picks 160 / 320-column tiles), no fused GEGLU, unbatched;
    * SASPA_ERANGE otherwise.  Deterministic (fixed summation order; no atomics). */
   float* gn_stats;

@@ -169,10 +169,10 @@ __device__ __forceinline__ void gn_tile_stats(const bf16_t* ct, const int cp, co
     for (int r = rg; r < nrows; r += rgs) {
       const uint32_t* src = reinterpret_cast<const uint32_t*>(ct + r * cp + u * unit);
       for (int j = 0; j < unit; j += 2) {
-        const uint32_t w = src[j >> 1];
-        const float a = __builtin_bit_cast(float, w << 16), b = __builtin_bit_cast(float, w & 0xffff0000u);
-        sm += a + b;
-        sq += a * a + b * b;
+        // two bf16 per dword: v_dot2c_f32_bf16 against (1, 1) and against itself -- 2 VALU per pair instead of 6
+        const bf16x2_t w = __builtin_bit_cast(bf16x2_t, src[j >> 1]);
+        sm = __builtin_amdgcn_fdot2_f32_bf16(w, __builtin_bit_cast(bf16x2_t, 0x3F803F80u), sm, false);
+        sq = __builtin_amdgcn_fdot2_f32_bf16(w, w, sq, false);
       }
     }
     scratch[(rg * nunits + u) * 2] = sm;

@@ -911,10 +911,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SaspaGemmParam
   }
 }
 
-// split-K reduce + epilogue + GroupNorm statistics (SaspaGemmParams.gn_stats): one workgroup per (128-row block, 160-column
-// slab); the finished bf16 slab is staged in LDS like a GEMM tile and gn_tile_stats reads it.  bf16 only.
+// split-K reduce + epilogue + GroupNorm statistics (SaspaGemmParams.gn_stats): one workgroup per (128-row block, 80-column
+// slab) -- 512 - 1024 workgroups on the 16x16 / 32x32 levels, two per CU; four rows per trip (4 x ksplit 16-byte loads in
+// flight per lane: the pass is bandwidth bound, the first version with one row per trip ran at half the plain reduce's rate);
+// the finished bf16 slab is staged in LDS like a GEMM tile and gn_tile_stats reads it.  bf16 only.
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const SaspaGemmParams p, int ksplit) {
-  constexpr int BR = 128, BC = 160, CP = BC + 8;
+  constexpr int BR = 128, BC = 80, CP = BC + 8, C4 = BC / 4, U = 4;
   __shared__ __attribute__((aligned(16))) bf16_t ct[BR * CP + 4 * 256];
   const int tid = threadIdx.x;
   const int rb = blockIdx.x, cs = blockIdx.y;
@@ -923,35 +925,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const SaspaGem
   bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
   const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
   const int nrows = min(BR, p.M - rb * BR);
-  for (int q = tid; q < nrows * (BC / 4); q += 256) {
-    const int row = q / (BC / 4), c4 = q - row * (BC / 4);
-    const int m = rb * BR + row, n = cs * BC + c4 * 4;
-    float4 a = *reinterpret_cast<const float4*>(p.workspace + (long long)m * p.N + n);
+  const int total = nrows * C4;
+  for (int q0 = tid; q0 < total; q0 += U * 256) {
+    float4 a[U];
+    int row[U], c4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = min(q0 + u * 256, total - 1);           // clamped duplicates are recomputed, never stored twice (below)
+      row[u] = q / C4;
+      c4[u] = q - row[u] * C4;
+      a[u] = *reinterpret_cast<const float4*>(p.workspace + (long long)(rb * BR + row[u]) * p.N + cs * BC + c4[u] * 4);
+    }
     for (int s = 1; s < ksplit; ++s) {
-      const float4 b = *reinterpret_cast<const float4*>(p.workspace + s * slab + (long long)m * p.N + n);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    float v[4] = {a.x, a.y, a.z, a.w};
-    if (p.bias) {
-      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-      v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-    }
-    if (p.rowvec) {
-      const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)(m / hw) * p.ldrv + n);
-      v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 b = *reinterpret_cast<const float4*>(p.workspace + s * slab + (long long)(rb * BR + row[u]) * p.N + cs * BC + c4[u] * 4);
+        a[u].x += b.x; a[u].y += b.y; a[u].z += b.z; a[u].w += b.w;
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = act_pre(p.act, v[r] * p.alpha);
-    if (res) {
-      float rr[4];
-      Elem<bf16_t>::load4(res + (long long)m * p.ldr + n, rr);
+    for (int u = 0; u < U; ++u) {
+      if (q0 + u * 256 >= total) continue;
+      const int m = rb * BR + row[u], n = cs * BC + c4[u] * 4;
+      float v[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+      if (p.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (p.rowvec) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)(m / hw) * p.ldrv + n);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += rr[r];
+      for (int r = 0; r < 4; ++r) v[r] = act_pre(p.act, v[r] * p.alpha);
+      if (res) {
+        float rr[4];
+        Elem<bf16_t>::load4(res + (long long)m * p.ldr + n, rr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = act_post(p.act, v[r]);
+      Elem<bf16_t>::store4(out + (long long)m * p.ldo + n, v);
+      Elem<bf16_t>::store4(ct + row[u] * CP + c4[u] * 4, v);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = act_post(p.act, v[r]);
-    Elem<bf16_t>::store4(out + (long long)m * p.ldo + n, v);
-    Elem<bf16_t>::store4(ct + row * CP + c4 * 4, v);
   }
   __syncthreads();
   gn_tile_stats<256>(ct, CP, nrows, BC / p.gn_unit, p.gn_unit, reinterpret_cast<float*>(ct + BR * CP),
@@ -1008,6 +1025,36 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   return 0;
 }
 
+// K-split of the 8-wave kernel from a cost model instead of "about one workgroup per CU" (round 3): with t tiles and ks slices
+// the launch takes ceil(t * ks / 256) ROUNDS of workgroups, each c0 + (K-tiles per slice) * c1 long, plus a reduce pass
+// over ks fp32 slabs.  The old rule rounded 256 / t to the nearest integer, which at the tile counts of non-square images
+// (88 / 96 / 176 tiles at 512x704 / 512x768) lands just ABOVE a whole number of rounds -- 264 workgroups = two rounds at
+// half occupancy.  Constants fitted on tools/conv_variant_sweep.py (profiles/r3_conv_sweep_704.txt): c0 = 20 us per workgroup
+// (prologue, epilogue, launch), c1 = 1.34 us per 64-deep K-tile of a 256 x 320 tile (x 0.8 for 256 x 256), reduce at 4 TB/s.
+// The wave-specialised kernel runs one workgroup per CU: t tiles take ceil(t / 256) rounds.  352 tiles (the 16x22 level of a
+// 512x704 image) would be two rounds at 69 %; the 4-wave tiles (two workgroups per CU) take those in one.  SASPA_GEMM_KSPLIT_MODEL=0
+// restores the round-2 rule (any 256 <= t < 512).
+static bool ws_round_ok(long long t) {
+  static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);
+  if (!model) return true;
+  const long long rounds = (t + 255) / 256;
+  return t * 100 >= rounds * 256 * 85;
+}
+
+static int pp_choose_ksplit(long long t, int ktiles, long long mn, int fn) {
+  const double c0 = 20.0, c1 = fn == 5 ? 1.34 : 1.07;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ks = 1; ks <= 8; ++ks) {
+    if (ks > 1 && ktiles / ks < 8) break;
+    const long long rounds = (t * ks + 255) / 256;
+    double cost = (double)rounds * (c0 + (double)((ktiles + ks - 1) / ks) * c1);
+    if (ks > 1) cost += 5.0 + (4.0 * ks + 4.0) * (double)mn / 4.0e6;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
+  }
+  return best;
+}
+
 template <typename T>
 int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const long long nb = (long long)p.nb1 * p.nb2;
@@ -1024,7 +1071,9 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       if (p.variant == SASPA_GEMM_WIDE) return can ? saspa_gemm_pp_launch(p, s, ksplit, 5) : SASPA_ERANGE;
       if (can && pp_mode_g != 0 && p.variant == SASPA_GEMM_AUTO && p.K >= 960) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / 320);
-        if (t >= 192) return saspa_gemm_pp_launch(p, s, 1, 5);
+        static const bool model_g = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);
+        if (model_g && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, 5);
+        if (t >= (model_g ? 144 : 192) && (!model_g || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, 5);
         static const bool wide_ks_g = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);
         if (wide_ks_g && ksplit > 1 && p.K >= 4096 && t >= 24 && t * ksplit >= 128) return saspa_gemm_pp_launch(p, s, ksplit, 5);
       }
@@ -1079,7 +1128,13 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
       if (fn) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
-        if (t >= 192) return saspa_gemm_pp_launch(p, s, 1, fn);   // one wave of tiles or more: no split-K
+        static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);   // A/B knob
+        // long K, one slice chosen by the cost model (suggest_ksplit) and at least half the CUs busy: still the wide kernel
+        if (model && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, fn);
+        // 3/4 of a wave of tiles or more: no split-K.  (144 <= t < 192 is the 512x704 / 512x768 buckets' 32x44 / 32x48 level:
+        // 176 / 192 workgroups in one round against 704 / 768 4-wave tiles in two rounds of 512 slots -- 74 vs 124 us at
+        // (22528, 640, 2560); t = 128, the 512x512 case, ties and stays on the 4-wave tiles)
+        if (t >= (model ? 144 : 192) && (!model || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, fn);
         // fewer wide tiles than CUs but a long K (the 3x3 convs of the 32x32 / 16x16 levels): the wide kernel on K
         // slices -- measured 1.17-1.45x the 128x160 kernel at M = 16 384 / 4 096 (tools/conv_variant_sweep.py)
         static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);   // A/B knob
@@ -1100,7 +1155,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
     static const int ws_max = getenv("SASPA_GEMM_WS_MAXTILES") ? atoi(getenv("SASPA_GEMM_WS_MAXTILES")) : 512;
     if (ws_on && p.variant == SASPA_GEMM_AUTO && ksplit == 1 && nb == 1 && saspa_gemm_ws_eligible(p)) {
       const long long t = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
-      if (t >= 256 && t < ws_max) return saspa_gemm_ws_launch(p, s);
+      if (t >= 256 && t < ws_max && ws_round_ok(t)) return saspa_gemm_ws_launch(p, s);
     }
   }
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb * ksplit;
@@ -1127,19 +1182,27 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
     const int bn_t = (p.N % 160 == 0) ? 160 : 128;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + bn_t - 1) / bn_t);
     if (ws_on && !p.gn_stats && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 && t128 >= 256 && t128 < ws_max &&
-        saspa_gemm_ws_eligible(p))
+        ws_round_ok(t128) && saspa_gemm_ws_eligible(p))
       return 1;
   }
   if (wide_ks && p.dtype == SASPA_BF16 && p.K >= 4096 && saspa_gemm_pp_eligible(p)) {
     const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
     if (fn) {
       const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
-      if (t >= 192) return 1;                       // the wide kernel fills the chip without slicing K
-      if (t >= 24) {
-        int ks = (int)((256 + t / 2) / t);          // about one workgroup per CU
-        ks = ks < 2 ? 2 : (ks > 8 ? 8 : ks);
-        while (ks > 1 && ktiles / ks < 8) --ks;
-        if (ks > 1) return ks;
+      static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);   // A/B knob
+      if (!model) {
+        if (t >= 192) return 1;                     // the wide kernel fills the chip without slicing K
+        if (t >= 24) {
+          int ks = (int)((256 + t / 2) / t);        // about one workgroup per CU
+          ks = ks < 2 ? 2 : (ks > 8 ? 8 : ks);
+          while (ks > 1 && ktiles / ks < 8) --ks;
+          if (ks > 1) return ks;
+        }
+      } else if (t >= 24) {
+        // rounds x slice length + reduce: pp_choose_ksplit; a single slice is taken on the wide kernel too when it leaves at
+        // least half the CUs busy (dispatch() applies the same rule)
+        const int ks = pp_choose_ksplit(t, ktiles, (long long)p.M * p.N, fn);
+        if (ks > 1 || t >= 128) return ks;
       }
     }
   }
@@ -1175,7 +1238,7 @@ int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles
 
 int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   if (p.gn_stats) {        // saspa_gemm checked: bf16, N % 160 == 0, 160 % gn_unit == 0
-    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 127) / 128, p.N / 160), dim3(256), 0, s, p, ksplit);
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 127) / 128, p.N / 80), dim3(256), 0, s, p, ksplit);
     SASPA_CHECK_LAUNCH();
     return 0;
   }
@@ -1248,7 +1311,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (p.gn_stats) {
     // epilogue GroupNorm statistics (ABI 12): bf16, whole 160-column tiles whose first column is a multiple of the unit
     if (p.dtype != SASPA_BF16 || p.act == SASPA_ACT_GEGLU || (long long)p.nb1 * p.nb2 != 1) return SASPA_ERANGE;
-    if (p.gn_unit < 2 || p.gn_unit > 16 || (p.gn_unit & 1) || (160 % p.gn_unit) != 0 || (p.N % 160) != 0) return SASPA_ERANGE;
+    if (p.gn_unit < 2 || p.gn_unit > 16 || (p.gn_unit & 1) || (80 % p.gn_unit) != 0 || (p.N % 160) != 0) return SASPA_ERANGE;
     if ((p.ldo % 8) != 0 || (p.residual && (p.ldr % 8) != 0)) return SASPA_ERANGE;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -140,7 +140,7 @@ def _gn_stats_for(p, out, gn_unit, b, hw, n):
     shape allows it: bf16, whole 128-row blocks per image, whole 160-column tiles, dense output rows."""
     if not gn_unit or not gn_fusion_enabled() or out.dtype != torch.bfloat16:
         return None
-    if hw % 128 or n % 160 or 160 % gn_unit or gn_unit % 2 or gn_unit > 16 or out.shape[-1] != n or p.ldo % 8 or (p.residual and p.ldr % 8):
+    if hw % 128 or n % 160 or 80 % gn_unit or gn_unit % 2 or gn_unit > 16 or out.shape[-1] != n or p.ldo % 8 or (p.residual and p.ldr % 8):
         return None
     stats = torch.empty((b * hw // 128, n // gn_unit, 2), device=out.device, dtype=torch.float32)
     p.gn_stats, p.gn_unit = _ptr(stats), int(gn_unit)

@@ -323,7 +323,9 @@ def run(args):
     n_gpus = world
 
     cfgs = CFG.tiny() if args.tiny else CFG.SD15
-    pipe = StableDiffusionControlNetPipeline.from_synthetic(cfgs, seed=0).to(dev, torch.bfloat16)
+    from saspa_aug_amd import weights as W
+    # N ranks: the node's first rank draws the 2.8 GB of random weights once, the others map its /dev/shm file
+    pipe = StableDiffusionControlNetPipeline(W.synth_family_shared(cfgs, 0, dist, "tiny" if args.tiny else "sd15"), cfgs).to(dev, torch.bfloat16)
     if args.no_safety_checker:
         pipe.safety_checker = None
     b, res, s = args.batch, args.res, args.ddim_steps

@@ -500,6 +500,34 @@ def synth_family(cfgs, seed=0):
     return fam
 
 
+def synth_family_shared(cfgs, seed=0, dist=None, tag="family"):
+    """`synth_family` for one-process-per-GPU jobs (bench.py --gpus N): the first rank of each node draws the family ONCE and
+    parks it in /dev/shm; the other ranks of the node map that file (torch.load(mmap=True): shared pages, no second copy in
+    RAM) instead of running N CPU synthesisers side by side in one cgroup.  The file is unlinked as soon as every rank has
+    mapped it.  `dist`: an initialised torch.distributed module (None / world 1 -> plain synth_family)."""
+    import os
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return synth_family(cfgs, seed)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(dist.get_rank())))
+    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                        f"saspa_synth_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{tag}_{seed}.pt")
+    fam = None
+    if local_rank == 0:
+        fam = synth_family(cfgs, seed)
+        torch.save(fam, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    dist.barrier()
+    if fam is None:
+        fam = torch.load(path, mmap=True, weights_only=True)
+    dist.barrier()
+    if local_rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return fam
+
+
 _LEGACY_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
 
 

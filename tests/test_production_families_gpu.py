@@ -30,11 +30,12 @@ def _metrics(img, x, ref_img, ref_x):
 
 
 def test_blip_full_width_bf16_graph_vs_oracle(dev, heavy_budget):
-    """configs[2]: full-width Q-Former (494 M) + context CLIP + SD-1.5 UNet / ControlNet / VAE, batch 4, 512x512, 3 PLMS steps
-    (4 network evaluations), conditioning scale 1.0 (none is passed, run_aug/run_aug.py:262-265)."""
+    """configs[2]: full-width Q-Former (494 M) + context CLIP + SD-1.5 UNet / ControlNet / VAE, batch 8 (the batch BASELINE
+    configs[2] states), 512x512, 3 PLMS steps (4 network evaluations), conditioning scale 1.0 (none is passed,
+    run_aug/run_aug.py:262-265)."""
     cfgs = CFG.BLIP_DIFFUSION
     fam = W.synth_family(cfgs, seed=0)
-    b, res, steps = 4, 512, 3
+    b, res, steps = 8, 512, 3
     nt = cfgs["text"]["max_pos"] - cfgs["qformer"]["num_query"]
     v = cfgs["text"]["vocab"]
     ids = np.random.RandomState(1).randint(0, v - 2, (b, nt))

@@ -57,6 +57,7 @@ extern "C" {
 #define SASPA_GEMM_TILED 1 /* 4-wave 128x160 / 128x128 / 64x64 tiles, two workgroups per CU */
 #define SASPA_GEMM_WIDE 2  /* 8-wave 256x320 / 256x256 tile, one workgroup per CU */
 #define SASPA_GEMM_WS 3    /* wave-specialised 128x160 tile (12 waves: 4 MMA + 4 loader + 4 epilogue): short-K bf16 layers */
+#define SASPA_GEMM_AS 4    /* A-stationary: 256 rows x K = 320 held in registers, W streamed through LDS (level-0 pointwise layers) */
 
 #define SASPA_KORDER_TAP 0
 #define SASPA_KORDER_CHUNK 1
@@ -126,7 +127,29 @@ typedef struct SaspaGemmParams {
    * SASPA_ERANGE otherwise.  Deterministic (fixed summation order; no atomics). */
   float* gn_stats;
   int gn_unit;
+  /* LayerNorm fused into the operand load, and a transposed second output (ABI 13): the A-stationary kernel for pointwise
+   * layers with K = 320 (the level-0 transformer blocks: each workgroup keeps 256 rows of A in REGISTERS across every column
+   * tile, so the rows can be normalised once, in place, before the first product).
+   * ln_gamma != NULL: A is replaced by LayerNorm(A) over its K channels (two-pass mean / variance in fp32, eps = ln_eps,
+   * affine ln_gamma / ln_beta [K], rounded to bf16 -- the arithmetic of saspa_layernorm) before the product; removes the
+   * LayerNorm launch and its 2 x M x K bytes.  Only problems saspa_gemm_as_eligible() accepts; SASPA_ERANGE otherwise.
+   * out_t != NULL: output columns n >= n_split are written TRANSPOSED to out_t instead of out: element (row, n) goes to
+   * out_t[(row / rows_per_batch) * st + (n - n_split) * ldt + row % rows_per_batch] -- the V^T operand of saspa_flash_attn
+   * out of the same launch as Q | K (BasicTransformerBlock.attn1: one read of the normalised tokens instead of two
+   * launches).  n_split % 64 == 0, rows_per_batch % 32 == 0, same eligibility. */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  void* out_t;
+  int ldt;
+  long long st;
+  int n_split;
+  int rows_per_batch;
 } SaspaGemmParams;
+/* 1 if saspa_gemm would run the problem on the A-stationary kernel (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at
+ * least 192 blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or
+ * fused GEGLU): the only kernel that takes ln_gamma / out_t. */
+int saspa_gemm_as_eligible(const SaspaGemmParams* p);
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 /* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):
  * the caller allocates ksplit*M*N floats, sets p->ksplit / p->workspace and calls saspa_gemm.  Long-K layers with

@@ -23,6 +23,8 @@ class GemmParams(C.Structure):
         ("sa1", C.c_longlong), ("sa2", C.c_longlong), ("sw1", C.c_longlong), ("sw2", C.c_longlong),
         ("so1", C.c_longlong), ("so2", C.c_longlong), ("ksplit", C.c_int), ("workspace", C.c_void_p),
         ("variant", C.c_int), ("korder", C.c_int), ("gn_stats", C.c_void_p), ("gn_unit", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("out_t", C.c_void_p), ("ldt", C.c_int),
+        ("st", C.c_longlong), ("n_split", C.c_int), ("rows_per_batch", C.c_int),
     ]
 
 
@@ -69,6 +71,7 @@ _I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 SYMBOLS = {
     "saspa_gemm": (_I, [C.POINTER(GemmParams), _P]),
     "saspa_gemm_suggest_ksplit": (_I, [C.POINTER(GemmParams)]),
+    "saspa_gemm_as_eligible": (_I, [C.POINTER(GemmParams)]),
     "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),

@@ -15,3 +15,6 @@ __attribute__((visibility("hidden"))) int saspa_gemm_npart8(const SaspaGemmParam
 // wave-specialised 8-wave kernel for short-K bf16 layers (saspa_gemm_ws.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s);
 __attribute__((visibility("hidden"))) bool saspa_gemm_ws_eligible(const SaspaGemmParams& p);
+// A-stationary kernel for K = 320 pointwise layers (saspa_gemm_as.hip): fused LayerNorm, transposed second output
+__attribute__((visibility("hidden"))) int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s);
+__attribute__((visibility("hidden"))) bool saspa_gemm_as_ok(const SaspaGemmParams& p);

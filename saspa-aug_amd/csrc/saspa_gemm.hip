@@ -1058,6 +1058,20 @@ static int pp_choose_ksplit(long long t, int ktiles, long long mn, int fn) {
 template <typename T>
 int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   const long long nb = (long long)p.nb1 * p.nb2;
+  // A-stationary kernel (saspa_gemm_as.hip): pointwise bf16 layers with K = 320 and enough rows to fill the chip; the only
+  // kernel that takes a fused LayerNorm / a transposed second output
+  if constexpr (sizeof(T) == 2) {
+    if (p.variant == SASPA_GEMM_AS) return saspa_gemm_as_launch(p, s);
+    if (p.variant == SASPA_GEMM_AUTO && saspa_gemm_as_ok(p)) {
+      // a fused LayerNorm / transposed tail exists on this kernel only; otherwise it is taken where it measured faster than the
+      // tiled / wave-specialised kernels (tools/as_bench.py): whole rounds of 256-row blocks, or -- with a ragged last round
+      // (352 blocks at 512x704) -- the layers with a residual or 640 columns, not the GEGLU projection
+      const long long blocks = (p.M + 255) / 256;
+      const bool whole = blocks * 100 >= ((blocks + 255) / 256) * 256 * 85;
+      if (p.ln_gamma || p.out_t || whole || (p.act != SASPA_ACT_GEGLU && (p.residual || p.N >= 640))) return saspa_gemm_as_launch(p, s);
+    }
+  }
+  if (p.ln_gamma || p.out_t || p.variant == SASPA_GEMM_AS) return SASPA_ERANGE;
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
   const bool n160 = (p.N % 160) == 0;
   if (p.gn_stats) {
@@ -1272,7 +1286,13 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
   if (p.K != p.kh * p.kw * (p.c0 + p.c1)) return SASPA_ERANGE;
   if ((long long)p.batch * p.hout * p.wout != p.M) return SASPA_ERANGE;
   if (p.lda0 < p.c0 || (p.c1 > 0 && p.lda1 < p.c1) || p.ldw < p.K) return SASPA_ERANGE;
-  if (p.act != SASPA_ACT_GEGLU && p.ldo < p.N) return SASPA_ERANGE;
+  if (p.act != SASPA_ACT_GEGLU && p.ldo < (p.out_t ? p.n_split : p.N)) return SASPA_ERANGE;
+  if (p.ln_gamma && !p.ln_beta) return SASPA_EINVAL;
+  if (p.out_t) {      // transposed tail columns (ABI 13): geometry is checked here, eligibility of the kernel in dispatch()
+    if (p.n_split < 0 || p.n_split > p.N || p.rows_per_batch <= 0 || p.M % p.rows_per_batch || p.ldt < p.rows_per_batch) return SASPA_ERANGE;
+    if (p.M / p.rows_per_batch > 1 && p.st < (long long)(p.N - p.n_split) * p.ldt) return SASPA_ERANGE;
+    if ((reinterpret_cast<uintptr_t>(p.out_t) & 1u)) return SASPA_EALIGN;
+  }
   // the window of every output pixel must come from the declared input extent
   {
     const int hv = p.upsample ? 2 * p.hin : p.hin, wv = p.upsample ? 2 * p.win : p.win;
@@ -1298,7 +1318,7 @@ extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {
     const int bk = p.dtype == SASPA_BF16 ? 64 : 32;
     if (p.c0 % bk || p.c1 % bk) return SASPA_ERANGE;
   }
-  if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_WS) return SASPA_EINVAL;
+  if (p.variant < SASPA_GEMM_AUTO || p.variant > SASPA_GEMM_AS) return SASPA_EINVAL;
   if (p.act == SASPA_ACT_GEGLU) {
     // fused GEGLU: bf16 only, whole tiles, weights pre-interleaved per tile (see header)
     const int bn = (p.N % 160) == 0 ? 160 : 128;

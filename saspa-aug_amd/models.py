@@ -191,6 +191,10 @@ class _Net:
             pk.attn(t + ".attn2", False, qscale=qs)
             if qs is not None:
                 self.qscaled[t] = qs
+            if self.dtype == torch.bfloat16 and c == 320 and (t + ".attn1.qk.b") not in self.p:
+                # level-0 blocks: [to_q; to_k; to_v] in one matrix for the A-stationary kernel (LayerNorm fused, V^T written
+                # transposed by the same launch: ops.linear(ln=, out_t=)); the separate matrices stay for the other sizes
+                self.p[t + ".attn1.qkv.w"] = torch.cat([self.p[t + ".attn1.qk.w"], self.p[t + ".attn1.v.w"][:, :c]], 0).contiguous()
             packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
                 if self.dtype == torch.bfloat16 else None
             if packed is not None:          # bf16: GEGLU fused into the projection's epilogue
@@ -335,10 +339,17 @@ class _Net:
         h = ops.conv(h, p[pfx + ".proj_in.w"], p[pfx + ".proj_in.b"]).view(b, n, c)
         for d in range(depth):
             t = f"{pfx}.transformer_blocks.{d}"
-            # self-attention
-            n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
-            qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
-            vt = project_vt(n1, p[t + ".attn1.v.w"], n)
+            # self-attention.  Level 0 of a full-size batch: LayerNorm + Q | K + V^T in ONE launch of the A-stationary kernel
+            # (saspa_gemm_as.hip) instead of three launches that each re-read the tokens
+            wqkv = p.get(t + ".attn1.qkv.w")
+            fuse = wqkv is not None and t not in self.fp8_blocks and n % 32 == 0 and ops.linear_ln_fusable(h, wqkv, n_out=2 * c)
+            if fuse:
+                vt = torch.empty((b, c, n), device=h.device, dtype=h.dtype)
+                qk = ops.linear(h, wqkv, None, ln=(p[t + ".norm1.g"], p[t + ".norm1.b"], 1e-5), out_t=vt, n_split=2 * c, rows_per_batch=n)
+            else:
+                n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
+                qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
+                vt = project_vt(n1, p[t + ".attn1.v.w"], n)
             pre = t in self.qscaled
             o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
             h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
@@ -355,17 +366,24 @@ class _Net:
                 h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
                 continue
             # cross-attention against the cached text K / V^T
-            n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
-            q = ops.linear(n2, p[t + ".attn2.q.w"])
+            if fuse and ops.linear_ln_fusable(h, p[t + ".attn2.q.w"]):
+                q = ops.linear(h, p[t + ".attn2.q.w"], ln=(p[t + ".norm2.g"], p[t + ".norm2.b"], 1e-5))
+            else:
+                n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
+                q = ops.linear(n2, p[t + ".attn2.q.w"])
             k, vtc, nk = self.ctx_kv[t]
             o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
             h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
-            n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
-            if t in self.fused_geglu:
-                ff = ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU)
+            if fuse and t in self.fused_geglu and ops.linear_ln_fusable(h, p[t + ".ff.net.0.proj.w"], act=ops.ACT_GEGLU):
+                ff = ops.linear(h, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU,
+                                ln=(p[t + ".norm3.g"], p[t + ".norm3.b"], 1e-5))
             else:
-                ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
+                n3 = ops.layernorm(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
+                if t in self.fused_geglu:
+                    ff = ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU)
+                else:
+                    ff = ops.geglu(ops.linear(n3, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]))
             h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
         return ops.conv(h.view(b, hh, ww, c), p[pfx + ".proj_out.w"], p[pfx + ".proj_out.b"], residual=x, gn_unit=self.gn_unit)
 

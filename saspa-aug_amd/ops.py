@@ -18,7 +18,7 @@ ACT_GELU = 4        # saspa_activation only: erf GELU (BERT / Q-Former)
 ACT_GEGLU = 3       # saspa_gemm only: fused GEGLU epilogue (bf16, weights packed by weights.pack_geglu)
 ACT_RELU = 5        # saspa_gemm / saspa_activation: ReLU (before the residual add)
 ACT_ADD_RELU = 6    # saspa_gemm only: ReLU AFTER the residual add (ResNet bottleneck)
-GEMM_AUTO, GEMM_TILED, GEMM_WIDE, GEMM_WS = 0, 1, 2, 3   # SaspaGemmParams.variant
+GEMM_AUTO, GEMM_TILED, GEMM_WIDE, GEMM_WS, GEMM_AS = 0, 1, 2, 3, 4   # SaspaGemmParams.variant
 
 
 # Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)
@@ -212,21 +212,9 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     return out
 
 
-def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0, ksplit=None):
-    """x: [..., K] (last dim contiguous, uniform row pitch) @ w[N, K]^T -> [..., round8(N)]."""
-    _check_dev(x, w, bias, residual, out)
-    lib = _lib.load()
-    k = x.shape[-1]
-    x2 = x.reshape(-1, k) if x.dim() != 2 else x
-    m = x2.shape[0]
-    n = w.shape[0]
-    if out is None:
-        nc = round8(n // 2 if act == ACT_GEGLU else n)
-        out = (torch.zeros if (nc != n and act != ACT_GEGLU) else torch.empty)((m, nc), device=x.device, dtype=x.dtype)
-    o2 = out.view(-1, out.shape[-1]) if out.dim() != 2 else out
-    r2 = None if residual is None else (residual.reshape(-1, residual.shape[-1]) if residual.dim() != 2 else residual)
+def _linear_params(x2, w, bias, r2, o2, alpha, act, rowvec, variant, m, n, k):
     p = _lib.GemmParams()
-    p.dtype = _gemm_dt(x)
+    p.dtype = _gemm_dt(x2)
     p.a0, p.a1, p.c0, p.c1 = _ptr(x2), None, k, 0
     p.lda0, p.lda1 = (x2.stride(0) if m > 1 else max(k, x2.stride(0))), 0
     p.batch, p.hin, p.win, p.hout, p.wout = 1, m, 1, m, 1
@@ -242,7 +230,56 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     p.ldo = o2.stride(0) if m > 1 else max(o2.shape[-1], o2.stride(0))
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
-    _ws = _set_splitk(p, m, n, k, x, ksplit) if act != ACT_GEGLU else None  # noqa: F841
+    return p
+
+
+def linear_ln_fusable(x, w, *, act=ACT_NONE, n_out=None):
+    """True if `linear(x, w, ..., ln=...)` / `out_t=` can run: the A-stationary kernel takes the problem
+    (saspa_gemm_as_eligible: bf16, K = 320, N % 64 == 0, >= 192 blocks of 256 rows; SASPA_GEMM_AS=0 turns it off)."""
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        return False
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k) if x.dim() != 2 else x
+    m, n = x2.shape[0], w.shape[0]
+    nc = (n // 2 if act == ACT_GEGLU else n) if n_out is None else n_out
+    p = _linear_params(x2, w, None, None, x2, 1.0, act, None, 0, m, n, k)
+    p.ldo = round8(nc)                    # the output a call would allocate (only its pitch / alignment are looked at)
+    return bool(_lib.load().saspa_gemm_as_eligible(C.byref(p)))
+
+
+def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0, ksplit=None,
+           ln=None, out_t=None, n_split=None, rows_per_batch=None):
+    """x: [..., K] (last dim contiguous, uniform row pitch) @ w[N, K]^T -> [..., round8(N)].
+    ln = (gamma, beta, eps): LayerNorm over K applied to x inside the launch (SaspaGemmParams.ln_gamma: the A-stationary
+    kernel only -- check `linear_ln_fusable` first; the library returns ERANGE otherwise).
+    out_t [B, N - n_split, ld] with n_split, rows_per_batch: output columns >= n_split are written transposed per batch of
+    rows_per_batch rows (the V^T operand of flash_attn next to Q | K); the returned tensor then has n_split columns."""
+    _check_dev(x, w, bias, residual, out, out_t)
+    lib = _lib.load()
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k) if x.dim() != 2 else x
+    m = x2.shape[0]
+    n = w.shape[0]
+    if out is None:
+        nc = round8(n // 2 if act == ACT_GEGLU else (n if out_t is None else n_split))
+        out = (torch.zeros if (nc != n and act != ACT_GEGLU and out_t is None) else torch.empty)((m, nc), device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, out.shape[-1]) if out.dim() != 2 else out
+    r2 = None if residual is None else (residual.reshape(-1, residual.shape[-1]) if residual.dim() != 2 else residual)
+    p = _linear_params(x2, w, bias, r2, o2, alpha, act, rowvec, variant, m, n, k)
+    if ln is not None:
+        g, b_, eps = ln
+        _check_dev(g, b_)
+        if g.dtype != torch.float32 or b_.dtype != torch.float32 or g.numel() < k or b_.numel() < k:
+            raise ValueError("LayerNorm gamma / beta must be fp32 vectors of K elements")
+        p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(g), _ptr(b_), float(eps)
+    if out_t is not None:
+        if out_t.dim() != 3 or out_t.stride(2) != 1 or out_t.dtype != x.dtype or n_split is None or not rows_per_batch:
+            raise ValueError("out_t must be [batch, N - n_split, ld] in the input dtype, with n_split and rows_per_batch given")
+        if out_t.shape[0] * rows_per_batch != m or out_t.shape[1] != n - n_split or out_t.shape[2] < rows_per_batch:
+            raise ValueError(f"out_t {tuple(out_t.shape)} does not hold {n - n_split} transposed columns of {m} rows in batches of {rows_per_batch}")
+        p.out_t, p.ldt, p.st = _ptr(out_t), out_t.stride(1), out_t.stride(0)
+        p.n_split, p.rows_per_batch = int(n_split), int(rows_per_batch)
+    _ws = _set_splitk(p, m, n, k, x, ksplit) if (act != ACT_GEGLU and ln is None and out_t is None) else None  # noqa: F841
     if act == ACT_GEGLU:
         p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),

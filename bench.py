@@ -391,7 +391,8 @@ def run(args):
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         roof = dict(bound="mfma",
                     kernel="implicit-GEMM conv / linear family: gemm_dma_kernel (LDS-DMA 128x160 / 128x128 tiles), gemm_pp_kernel "
-                           "(8-wave 256x320 / 256x256), gemm_ws_kernel (12-wave wave-specialised 128x160, one-wave tile counts); v_mfma_f32_16x16x32_bf16",
+                           "(8-wave 256x320 / 256x256), gemm_ws_kernel (12-wave wave-specialised 128x160, one-wave tile counts), gemm_as_kernel (A-stationary, "
+                           "K = 320 pointwise layers with fused LayerNorm); v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16",
                     achieved=round(achieved, 1), peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / BF16_PEAK_TFLOPS, 4), traffic=None,
                     launches=gm["launches"], avg_launch_us=round(gm["ms"] * 1e3 / gm["launches"], 2),

@@ -198,7 +198,6 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   auto nstores = [&](int u) __attribute__((always_inline)) -> int {
     return EPI == 1 ? 2 : ((transposed_tail && u * AS_BN >= p.n_split) ? 32 : 4);
   };
-  constexpr int NRES = RES ? 4 : 0;                // residual loads per wave per slice (16 bytes per lane, store layout)
   unsigned trow = kInvalid;
   if (transposed_tail && live) {
     const long long bi = row / p.rows_per_batch;
@@ -218,45 +217,21 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   const unsigned char* stg_rd = stg + (lane / LPR) * SPITCH + (lane % LPR) * 16;
   unsigned char* stg_wr = stg + m * SPITCH + h * 8;
 
-  // slice 0 has landed (this wave's share); slice 1 stays in flight.  (With a LayerNorm its gamma / beta loads -- younger than
-  // both DMAs -- were already waited for, which in order implies the same.)
-  wait_vm_dyn(ndma);
-
-  for (int step = 0; step < nslices; ++step) {
-    const int t = slice_of(step);          // the slice (64 output columns) of this step; ring slots / waits go by step
-    // This wave's share of slice t is in LDS once at most the operations issued after its DMA are outstanding: vector memory
-    // returns in order.  Those are (steps t-2 and t-1) stores(t-2), residual loads(t-1), DMA(t+1), stores(t-1); every one of
-    // them is issued unconditionally (out-of-range lanes / slices use the invalid offset), so the count is exact.
-    if (step == 1) wait_vm_dyn(NRES + ndma + nstores(slice_of(0)));
-    else if (step >= 2) wait_vm_dyn(nstores(slice_of(step - 2)) + NRES + ndma + nstores(slice_of(step - 1)));
-    // publishes slice t to the other waves; also: every wave is done reading slice t-1, the slot the DMA below overwrites
-    if (!(abl & 16)) __builtin_amdgcn_s_barrier();
-
-    // residual of this slice first (consumed after the MFMAs: the compiler's own wait then leaves the DMA in flight)
-    u32x4 rv[NST];
-    if (RES) {
-#pragma unroll
-      for (int i = 0; i < NST; ++i) rv[i] = buf_load(rsr, sr_off[i] == kInvalid ? kInvalid : sr_off[i] + t * AS_BN * 2, 0);
-    }
-    dma_slice(step + 2);
-
+  // ---- the two halves of a step ----
+  // mma(step): bias (delivered with the slice) as the accumulators' initial value, then 40 MFMAs in groups of 4 (two K-steps x
+  // two column blocks) with the W fragments of the next TWO groups in flight (LDS latency under several waves' reads is a
+  // few MFMAs long); the sched_barrier keeps the compiler from hoisting all 40 fragment reads (160 VGPRs) to the top
+  auto mma = [&](int step, f32x16 (&acc)[2]) __attribute__((always_inline)) {
     const unsigned char* fs = fbase + (step % AS_RING) * (AS_STAGE * 16);
-    // bias (delivered with the slice) is the accumulators' initial value
-    f32x16 acc[2];
-    {
-      const unsigned char* bs = reinterpret_cast<const unsigned char*>(lds) + ((step % AS_RING) * AS_STAGE + AS_BIAS_SLOT) * 16;
+    const unsigned char* bs = reinterpret_cast<const unsigned char*>(lds) + ((step % AS_RING) * AS_STAGE + AS_BIAS_SLOT) * 16;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + (nb * 8 + 2 * g + h) * 16);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + (nb * 8 + 2 * g + h) * 16);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[nb][4 * g + j] = bv[j];
-        }
-    }
-    // 40 MFMAs in groups of 4 (two K-steps x two column blocks) with the W fragments of the next TWO groups in flight (LDS
-    // latency under eight waves' reads is several MFMAs long); the sched_barrier keeps the compiler from hoisting all 40
-    // fragment reads (160 VGPRs) to the top
+        for (int j = 0; j < 4; ++j) acc[nb][4 * g + j] = bv[j];
+      }
     auto frag = [&](int s, int nb) __attribute__((always_inline)) -> u32x4 {
       if (abl & 1) return af[(s + nb) % AS_KS];
       return *reinterpret_cast<const u32x4*>(fs + foff[s & 3] + (nb * 32 * AS_PITCH * 16 + ((2 * s) & ~7) * 16));
@@ -281,12 +256,14 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // epilogue(t): slice t's 32 x 64 tile of this wave out of the accumulators; issues exactly nstores(t) vector-memory stores
+  auto epilogue = [&](int t, f32x16 (&acc)[2], const u32x4 (&rv)[NST]) __attribute__((always_inline)) {
     if (abl & 4) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"v"(acc[nb]));
-      continue;
+      return;
     }
-
     if (EPI == 0 && transposed_tail && t * AS_BN >= p.n_split) {
       // transposed columns: channel c of token `row` -> out_t[batch][c][token]; 32 consecutive tokens per lane group
 #pragma unroll
@@ -297,41 +274,83 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
           const unsigned short bits = (unsigned short)(pack2(acc[nb][i], 0.f) & 0xffffu);
           __builtin_amdgcn_raw_buffer_store_b16(bits, rst, (int)(trow == kInvalid ? kInvalid : trow + (unsigned)(c * p.ldt * 2)), 0, 0);
         }
+      return;
+    }
+    // stage the tile as bf16 (GEGLU: value * gelu(gate), 32 columns), read it back row-major, add the residual, store
+    if (EPI == 1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 o = {pack2(fast_gelu_mul(acc[0][4 * g], acc[1][4 * g]), fast_gelu_mul(acc[0][4 * g + 1], acc[1][4 * g + 1])),
+                         pack2(fast_gelu_mul(acc[0][4 * g + 2], acc[1][4 * g + 2]), fast_gelu_mul(acc[0][4 * g + 3], acc[1][4 * g + 3]))};
+        *reinterpret_cast<u32x2*>(stg_wr + g * 16) = o;
+      }
     } else {
-      // stage the tile as bf16 (GEGLU: value * gelu(gate), 32 columns), read it back row-major, add the residual, store
-      if (EPI == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const u32x2 o = {pack2(fast_gelu_mul(acc[0][4 * g], acc[1][4 * g]), fast_gelu_mul(acc[0][4 * g + 1], acc[1][4 * g + 1])),
-                           pack2(fast_gelu_mul(acc[0][4 * g + 2], acc[1][4 * g + 2]), fast_gelu_mul(acc[0][4 * g + 3], acc[1][4 * g + 3]))};
-          *reinterpret_cast<u32x2*>(stg_wr + g * 16) = o;
+          const u32x2 o = {pack2(acc[nb][4 * g], acc[nb][4 * g + 1]), pack2(acc[nb][4 * g + 2], acc[nb][4 * g + 3])};
+          *reinterpret_cast<u32x2*>(stg_wr + nb * 64 + g * 16) = o;
         }
-      } else {
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const u32x2 o = {pack2(acc[nb][4 * g], acc[nb][4 * g + 1]), pack2(acc[nb][4 * g + 2], acc[nb][4 * g + 3])};
-            *reinterpret_cast<u32x2*>(stg_wr + nb * 64 + g * 16) = o;
-          }
-      }
-      const int cbytes = EPI == 1 ? t * 32 * 2 : t * AS_BN * 2;
-#pragma unroll
-      for (int i = 0; i < NST; ++i) {
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH), hi = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH + 8);
-        u32x4 o = {lo.x, lo.y, hi.x, hi.y};
-        if (RES) {
-          // (the product was rounded to bf16 by the staging: two roundings, as Linear -> add in the reference and as the tiled kernels)
-          float a[8], r8[8];
-          unpack8(__builtin_bit_cast(uint4, o), a);
-          unpack8(__builtin_bit_cast(uint4, rv[i]), r8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] += r8[j];
-          o = __builtin_bit_cast(u32x4, pack8(a));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(o, rso, (int)(so_off[i] == kInvalid ? kInvalid : so_off[i] + cbytes), 0, 0);
-      }
     }
+    const int cbytes = EPI == 1 ? t * 32 * 2 : t * AS_BN * 2;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH), hi = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH + 8);
+      u32x4 o = {lo.x, lo.y, hi.x, hi.y};
+      if (RES) {
+        // (the product was rounded to bf16 by the staging: two roundings, as Linear -> add in the reference and as the tiled kernels)
+        float a[8], r8[8];
+        unpack8(__builtin_bit_cast(uint4, o), a);
+        unpack8(__builtin_bit_cast(uint4, rv[i]), r8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += r8[j];
+        o = __builtin_bit_cast(u32x4, pack8(a));
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(o, rso, (int)(so_off[i] == kInvalid ? kInvalid : so_off[i] + cbytes), 0, 0);
+    }
+  };
+
+  // ---- vmcnt bookkeeping ----
+  // This wave's share of a slice is in LDS once at most the vector-memory operations it issued AFTER that slice's DMA are
+  // outstanding (vector memory returns in order).  Every such operation below is issued unconditionally (out-of-range lanes /
+  // slices use the invalid offset), so a running count is exact: `issued` counts them, mark[k] is its value right after the
+  // DMA into ring slot k.  The prologue's wait leaves at most slice 1's DMA (the last thing issued) in flight.
+  // (With a LayerNorm its gamma / beta loads -- younger than both DMAs -- were already waited for, which implies the same.)
+  wait_vm_dyn(ndma);
+  int issued = 0;
+  int mark[AS_RING] = {-64, 0, 0};
+  auto wait_slice = [&](int step) __attribute__((always_inline)) {
+    if (step > 0) wait_vm_dyn(issued - mark[step % AS_RING]);
+  };
+  auto issue_dma = [&](int step) __attribute__((always_inline)) {
+    dma_slice(step);
+    issued += ndma;
+    mark[step % AS_RING] = issued;
+  };
+
+  // One phase per step, every wave the same: (residual loads,) DMA of the slice after next, MFMAs, epilogue.  The residual
+  // loads go first: consumed after the MFMAs, the compiler's own wait for them then leaves the DMA in flight.
+  // (Built and dropped: two wave groups half a step apart -- waves 0-3 in a slice's MFMAs while their SIMD partners 4-7 run the
+  // previous slice's epilogue, two barriers per step.  Bit-identical, and slower: the GEGLU projection level with the
+  // wave-specialised kernel (189 vs 189 us on its box) instead of 3-20 % ahead of it as this loop is on five boxes
+  // (profiles/r3_as_bench.txt); the extra barrier and the half-empty phases cost more than the matrix | VALU overlap returns.)
+  for (int step = 0; step < nslices; ++step) {
+    const int t = slice_of(step);
+    wait_slice(step);
+    // publishes slice t to the other waves; also: every wave is done reading slice t-1, the slot the DMA below overwrites
+    if (!(abl & 16)) __builtin_amdgcn_s_barrier();
+    u32x4 rv[NST];
+    if (RES) {
+#pragma unroll
+      for (int i = 0; i < NST; ++i) rv[i] = buf_load(rsr, sr_off[i] == kInvalid ? kInvalid : sr_off[i] + t * AS_BN * 2, 0);
+      issued += NST;
+    }
+    issue_dma(step + 2);
+    f32x16 acc[2];
+    mma(step, acc);
+    epilogue(t, acc, rv);
+    issued += nstores(t);
   }
 }
 

@@ -6,7 +6,7 @@ import math, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(HERE, "..", "saspa-aug_amd")
 VARIANTS = (("full", 0), ("no W fragment reads", 1), ("no MFMA", 2), ("no epilogue", 4), ("no DMA", 8), ("no barrier", 16),
-            ("MFMA only (no reads, epilogue, DMA)", 13), ("reads only", 14), ("epilogue only", 11), ("reads + MFMA", 12),
+            ("DMA + barriers only", 7), ("reads + MFMA (no epilogue, no DMA)", 12), ("epilogue only", 11),
             ("nothing but the A load + barriers", 15))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     cs = os.path.join(PKG, "csrc")

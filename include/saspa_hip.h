@@ -146,9 +146,10 @@ typedef struct SaspaGemmParams {
   int n_split;
   int rows_per_batch;
 } SaspaGemmParams;
-/* 1 if saspa_gemm would run the problem on the A-stationary kernel (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at
- * least 192 blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or
- * fused GEGLU): the only kernel that takes ln_gamma / out_t. */
+/* Non-zero if the A-stationary kernel can run the problem (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at least 192
+ * blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or fused GEGLU,
+ * 16-byte aligned operands, ldo % 8 == 0): the only kernel that takes ln_gamma / out_t.  2 = the row blocks also fill whole
+ * rounds of the 256 CUs (the sizes where it beats the other kernels on every layer shape), 1 = they do not. */
 int saspa_gemm_as_eligible(const SaspaGemmParams* p);
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 /* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):

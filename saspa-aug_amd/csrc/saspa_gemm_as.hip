@@ -397,4 +397,10 @@ int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s) {
   return 0;
 }
 
-extern "C" int saspa_gemm_as_eligible(const SaspaGemmParams* p) { return (p && saspa_gemm_as_ok(*p)) ? 1 : 0; }
+// 0: cannot run; 1: can; 2: can, and the row blocks fill whole rounds of the 256 CUs (>= 85 % of the last round) -- the sizes
+// where the kernel beats the wave-specialised one on the GEGLU projection too (tools/as_bench.py; 352 blocks at 512x704 do not)
+extern "C" int saspa_gemm_as_eligible(const SaspaGemmParams* p) {
+  if (!p || !saspa_gemm_as_ok(*p)) return 0;
+  const long long blocks = (p->M + AS_BM - 1) / AS_BM;
+  return blocks * 100 >= ((blocks + 255) / 256) * 256 * 85 ? 2 : 1;
+}

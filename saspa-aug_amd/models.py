@@ -375,7 +375,8 @@ class _Net:
             o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
             h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
-            if fuse and t in self.fused_geglu and ops.linear_ln_fusable(h, p[t + ".ff.net.0.proj.w"], act=ops.ACT_GEGLU):
+            # (with a ragged last round of row blocks -- 512x704 -- the wave-specialised kernel + LayerNorm is as fast: == 2)
+            if fuse and t in self.fused_geglu and ops.linear_ln_fusable(h, p[t + ".ff.net.0.proj.w"], act=ops.ACT_GEGLU) == 2:
                 ff = ops.linear(h, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU,
                                 ln=(p[t + ".norm3.g"], p[t + ".norm3.b"], 1e-5))
             else:

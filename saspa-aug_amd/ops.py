@@ -234,17 +234,18 @@ def _linear_params(x2, w, bias, r2, o2, alpha, act, rowvec, variant, m, n, k):
 
 
 def linear_ln_fusable(x, w, *, act=ACT_NONE, n_out=None):
-    """True if `linear(x, w, ..., ln=...)` / `out_t=` can run: the A-stationary kernel takes the problem
-    (saspa_gemm_as_eligible: bf16, K = 320, N % 64 == 0, >= 192 blocks of 256 rows; SASPA_GEMM_AS=0 turns it off)."""
+    """Non-zero if `linear(x, w, ..., ln=...)` / `out_t=` can run: the A-stationary kernel takes the problem
+    (saspa_gemm_as_eligible: bf16, K = 320, N % 64 == 0, >= 192 blocks of 256 rows; SASPA_GEMM_AS=0 turns it off).
+    2 = whole rounds of row blocks (the kernel wins on every layer shape), 1 = a ragged last round."""
     if not x.is_cuda or x.dtype != torch.bfloat16:
-        return False
+        return 0
     k = x.shape[-1]
     x2 = x.reshape(-1, k) if x.dim() != 2 else x
     m, n = x2.shape[0], w.shape[0]
     nc = (n // 2 if act == ACT_GEGLU else n) if n_out is None else n_out
     p = _linear_params(x2, w, None, None, x2, 1.0, act, None, 0, m, n, k)
     p.ldo = round8(nc)                    # the output a call would allocate (only its pitch / alignment are looked at)
-    return bool(_lib.load().saspa_gemm_as_eligible(C.byref(p)))
+    return int(_lib.load().saspa_gemm_as_eligible(C.byref(p)))
 
 
 def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None, rowvec=None, variant=0, ksplit=None,

@@ -504,19 +504,39 @@ def synth_family_shared(cfgs, seed=0, dist=None, tag="family"):
     """`synth_family` for one-process-per-GPU jobs (bench.py --gpus N): the first rank of each node draws the family ONCE and
     parks it in /dev/shm; the other ranks of the node map that file (torch.load(mmap=True): shared pages, no second copy in
     RAM) instead of running N CPU synthesisers side by side in one cgroup.  The file is unlinked as soon as every rank has
-    mapped it.  `dist`: an initialised torch.distributed module (None / world 1 -> plain synth_family)."""
+    mapped it.  If any node cannot park the file (no /dev/shm, or one too small -- containers default to 64 MB), every rank
+    falls back to drawing its own copy.  `dist`: an initialised torch.distributed module (None / world 1 -> plain synth_family)."""
     import os
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return synth_family(cfgs, seed)
     local_rank = int(os.environ.get("LOCAL_RANK", str(dist.get_rank())))
-    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
-                        f"saspa_synth_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{tag}_{seed}.pt")
-    fam = None
+    path = os.path.join("/dev/shm", f"saspa_synth_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{tag}_{seed}.pt")
+    fam, ok = None, True
     if local_rank == 0:
         fam = synth_family(cfgs, seed)
-        torch.save(fam, path + ".tmp")
-        os.replace(path + ".tmp", path)
-    dist.barrier()
+        try:
+            need = sum(t.numel() * t.element_size() for sd in fam.values() for t in sd.values())
+            st = os.statvfs("/dev/shm")
+            if st.f_bavail * st.f_frsize < need * 1.05 + (64 << 20):
+                raise OSError(f"/dev/shm has {st.f_bavail * st.f_frsize >> 20} MB free, the family needs {need >> 20} MB")
+            torch.save(fam, path + ".tmp")
+            os.replace(path + ".tmp", path)
+        except OSError:
+            ok = False
+            for f in (path + ".tmp", path):
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, ok)                      # also the "file is there" barrier
+    if not all(flags):                                     # some node could not park it: everyone draws its own
+        if local_rank == 0 and ok:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return fam if fam is not None else synth_family(cfgs, seed)
     if fam is None:
         fam = torch.load(path, mmap=True, weights_only=True)
     dist.barrier()

@@ -115,13 +115,16 @@ def test_error_isolation_marks_items_failed(tmp_path):
     assert sum(len(v) for v in body.values()) == st.count(1)
 
 
-def _synth_worker(rank, world, port, q):
+def _synth_worker(rank, world, port, q, small_shm=False):
     import torch.distributed as dist
     from saspa_aug_amd import config as CFG
     from saspa_aug_amd import weights as W
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if small_shm:                                     # a container's default 64 MB /dev/shm
+            real_statvfs = os.statvfs
+            os.statvfs = lambda p: type("S", (), dict(f_bavail=16, f_frsize=4096))() if p == "/dev/shm" else real_statvfs(p)
         calls = []
         real = W.synth_family
         W.synth_family = lambda cfgs, seed=0: (calls.append(seed), real(cfgs, seed))[1]
@@ -154,4 +157,21 @@ def test_shared_synthetic_family_is_drawn_once_per_node():
     ref = hashlib.sha256(b"".join(fam[k][n].numpy().tobytes() for k in sorted(fam) for n in sorted(fam[k]))).hexdigest()
     assert [g[1] for g in got] == [1, 0], "rank 1 ran its own synthesiser"
     assert got[0][2] == got[1][2] == ref
+    assert got[0][3] == [] and got[1][3] == []
+
+
+@pytest.mark.timeout(300)
+def test_shared_synthetic_family_falls_back_when_dev_shm_is_too_small():
+    """Every rank then draws its own copy (same tensors), nothing is left behind and nobody hangs at a barrier."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_synth_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [1, 1] and got[0][2] == got[1][2]
     assert got[0][3] == [] and got[1][3] == []

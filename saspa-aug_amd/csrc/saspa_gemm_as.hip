@@ -14,9 +14,11 @@
 //     consecutive output columns of ONE row per accumulator quad: bias is the accumulators' initial value, the store is 8
 //     bytes per quad, and the V^T operand of the attention kernel is a 2-byte-per-lane store with 32 consecutive tokens per
 //     channel (SaspaGemmParams.out_t) -- Q | K | V^T leave one launch.
-// Roofline of a slice per workgroup: 320 MFMAs (8 waves x 40) against 320 KB of LDS fragment reads (each wave reads the whole
-// slice): both 2 560 cycles per CU -- the kernel is LDS-read / MFMA co-bound at about half the MFMA peak, which is 2x what
-// the tiled kernels reach on these shapes (tools/as_bench.py).
+// Roofline of a slice per workgroup: 320 MFMAs (8 waves x 40) = 2 560 cycles of every SIMD's matrix pipe.  Measured with in-kernel
+// stamps (tools/as_stamps.py): a step takes 5 150 cycles on the plain layers and 6 470 with the GELU -- the MFMA groups with the
+// previous slice's epilogue and the next-but-one slice's DMA pieces dealt between them take 4 200-4 500 (each vector-memory
+// instruction costs the wave 100-200 issue cycles, ten of them per step), the DMA wait 300-400, the barrier skew the rest:
+// 40-50 % of the matrix-pipe bound, i.e. the level of the 8-wave conv kernel, on layers where the tiled kernels reach 20-25 %.
 #include <cstdlib>
 
 #include "common.h"
@@ -37,7 +39,10 @@ constexpr int AS_RING = 3;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // vmcnt <= n with n a run-time (wave-uniform) value: the instruction takes an immediate; 63 is the counter's maximum
-__device__ __forceinline__ void wait_vm_dyn(int n) {
+__device__ __forceinline__ void wait_vm_dyn(int n_any) {
+  // the count is wave-uniform by construction; say so, or the switch becomes a tree of exec-mask branches on a VGPR (measured:
+  // ~750 cycles per step on tools/as_stamps.py)
+  const int n = __builtin_amdgcn_readfirstlane(n_any);
 #define SASPA_W1(i) case i: wait_vm<i>(); break;
 #define SASPA_W8(i) SASPA_W1(i) SASPA_W1(i + 1) SASPA_W1(i + 2) SASPA_W1(i + 3) SASPA_W1(i + 4) SASPA_W1(i + 5) SASPA_W1(i + 6) SASPA_W1(i + 7)
   switch (n < 63 ? n : 63) {
@@ -73,11 +78,22 @@ constexpr int AS_BIAS_SLOT = 8 * AS_NDMA * 64;        // wave 7's extra DMA inst
 template <int EPI, bool RES, int GB>
 __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p, const int abl_arg) {
   // diagnostics (tools/as_ablate.py builds one library per value: a run-time switch would change the loop it measures):
-  // 1 no W fragment reads, 2 no MFMA, 4 no epilogue, 8 no DMA, 16 no barrier
+  // 1 no W fragment reads, 2 no MFMA, 4 no epilogue, 8 no DMA, 16 no barrier, 32 stores out of range (issued, no bytes move)
 #ifdef SASPA_AS_ABLATE
   constexpr int abl = SASPA_AS_ABLATE;
 #else
   constexpr int abl = 0;
+#endif
+  // diagnostics (-DSASPA_AS_STAMPS, tools/as_stamps.py): s_memtime of workgroup 0's waves 0 and 7 at four points of every step,
+  // kept in the last 2.5 KB of LDS (a global store per stamp would be a vector-memory operation the vmcnt arithmetic does not
+  // count) and copied to SaspaGemmParams.workspace (unused by this kernel otherwise) at the end: [wave 0 | wave 7][step][4]
+#ifdef SASPA_AS_STAMPS
+  __shared__ unsigned long long stamp_lds[2 * 40 * 4];
+  const bool stamping = blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && p.workspace;
+  unsigned long long* stamps = stamp_lds + (threadIdx.x ? 160 : 0);
+#define AS_STAMP(step_, k_) do { if (stamping && (step_) < 40) stamps[(step_) * 4 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AS_STAMP(step_, k_) do { } while (0)
 #endif
   __shared__ u32x4 lds[AS_RING * AS_STAGE + AS_STG_CHUNKS];
   const int tid = threadIdx.x;
@@ -124,22 +140,23 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
     const int tile = f / half;
     return tile * gb + (f - tile * half) + ((n >> 5) ? half : 0);
   };
-  // ALWAYS `ndma` wave-wide DMA instructions (the loop's vmcnt arithmetic counts them): a slice past the end loads zeros
-  auto dma_slice = [&](int step) __attribute__((always_inline)) {
-    u32x4* dst = lds + (step % AS_RING) * AS_STAGE + wave * AS_NDMA * 64;
+  // ALWAYS `ndma` wave-wide DMA instructions per slice (the loop's vmcnt arithmetic counts them): a slice past the end loads
+  // zeros.  Piece i < AS_NDMA: 64 chunks of W; piece AS_NDMA (wave 7 only): the slice's 64 biases (fp32, 16 lanes x 16 bytes).
+  auto dma_piece = [&](int step, int i) __attribute__((always_inline)) {
     const bool real = step < nslices;
     const int t = real ? slice_of(step) : 0;
     if (abl & 8) return;
-#pragma unroll
-    for (int i = 0; i < AS_NDMA; ++i) {
+    if (i < AS_NDMA) {
       const unsigned off = real ? (unsigned)(wrow(t, dn[i]) * p.ldw * 2 + dkc[i] * 16) : kInvalid;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(dst + i * 64), 16, (int)off, 0, 0, 0);
-    }
-    if (wave == 7) {
-      // bias of the slice's 64 columns (fp32, 16 lanes x 16 bytes) behind the slice
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lds + (step % AS_RING) * AS_STAGE + (wave * AS_NDMA + i) * 64), 16, (int)off, 0, 0, 0);
+    } else if (wave == 7) {
       const unsigned off = (real && has_bias && lane < 16) ? (unsigned)(wrow(t, 4 * lane) * 4) : kInvalid;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void_t*)(lds + (step % AS_RING) * AS_STAGE + AS_BIAS_SLOT), 16, (int)off, 0, 0, 0);
     }
+  };
+  auto dma_slice = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i <= AS_NDMA; ++i) dma_piece(step, i);
   };
   dma_slice(0);
   dma_slice(1);
@@ -211,17 +228,23 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
     const long long r = row0 + RPI * i + lane / LPR;
-    so_off[i] = r < p.M ? (unsigned)(r * p.ldo * 2 + (lane % LPR) * 16) : kInvalid;
+    so_off[i] = (r < p.M && !(abl & 32)) ? (unsigned)(r * p.ldo * 2 + (lane % LPR) * 16) : kInvalid;   // abl 32: stores issued, all out of range
     sr_off[i] = (RES && r < p.M) ? (unsigned)(r * p.ldr * 2 + (lane % LPR) * 16) : kInvalid;
   }
   const unsigned char* stg_rd = stg + (lane / LPR) * SPITCH + (lane % LPR) * 16;
   unsigned char* stg_wr = stg + m * SPITCH + h * 8;
 
-  // ---- the two halves of a step ----
-  // mma(step): bias (delivered with the slice) as the accumulators' initial value, then 40 MFMAs in groups of 4 (two K-steps x
-  // two column blocks) with the W fragments of the next TWO groups in flight (LDS latency under several waves' reads is a
-  // few MFMAs long); the sched_barrier keeps the compiler from hoisting all 40 fragment reads (160 VGPRs) to the top
-  auto mma = [&](int step, f32x16 (&acc)[2]) __attribute__((always_inline)) {
+  // ---- a step: the slice's MFMAs with the PREVIOUS slice's epilogue dealt into the gaps between them ----
+  // One wave carries two instruction streams (as the attention kernel does): the matrix pipe runs slice t while the VALU / LDS /
+  // store work of slice t-1 (GELU, packing, the staging round trip, the stores) is issued between its MFMA groups -- with the
+  // epilogue as a separate phase after the MFMAs the loop measured the SUM of the two (tools/as_ablate.py), because the
+  // per-slice barrier puts all eight waves in the same phase.  What slice t-1 leaves behind for that: its 32 x 64 tile packed
+  // to bf16 (16 registers; GEGLU: the two fp32 accumulator blocks, 32 registers).
+  // mma(step, acc, between): bias (delivered with the slice) as the accumulators' initial value, then 40 MFMAs in groups of 4
+  // (two K-steps x two column blocks) with the W fragments of the next TWO groups in flight; between(gi) runs after group gi's
+  // MFMAs; the sched_barrier pins the deal and keeps the compiler from hoisting all 40 fragment reads (160 VGPRs) to the top.
+  constexpr int NG = AS_KS / 2;
+  auto mma = [&](int step, f32x16 (&acc)[2], auto&& between) __attribute__((always_inline)) {
     const unsigned char* fs = fbase + (step % AS_RING) * (AS_STAGE * 16);
     const unsigned char* bs = reinterpret_cast<const unsigned char*>(lds) + ((step % AS_RING) * AS_STAGE + AS_BIAS_SLOT) * 16;
 #pragma unroll
@@ -236,7 +259,6 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
       if (abl & 1) return af[(s + nb) % AS_KS];
       return *reinterpret_cast<const u32x4*>(fs + foff[s & 3] + (nb * 32 * AS_PITCH * 16 + ((2 * s) & ~7) * 16));
     };
-    constexpr int NG = AS_KS / 2;
     u32x4 wf[3][4];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
@@ -254,52 +276,67 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
         if (abl & 2) asm volatile("" ::"v"(wf[gi % 3][j]), "v"(af[sx]));
         else acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gi % 3][j]), __builtin_bit_cast(bf16x8, af[sx]), acc[nb], 0, 0, 0);
       }
+      between(gi);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // epilogue(t): slice t's 32 x 64 tile of this wave out of the accumulators; issues exactly nstores(t) vector-memory stores
-  auto epilogue = [&](int t, f32x16 (&acc)[2], const u32x4 (&rv)[NST]) __attribute__((always_inline)) {
-    if (abl & 4) {
+  // What a finished slice hands to the next step
+  struct Done {
+    u32x2 pk[8];          // plain: quad (nb, g) of the tile as 4 bf16 (columns 32 nb + 8 g + 4 h ..+4 of row m)
+    f32x16 sv[2];         // GEGLU: value block, gate block
+  };
+  auto finish = [&](f32x16 (&acc)[2], Done& d) __attribute__((always_inline)) {
+    if (abl & 4) {               // (no epilogue: keep the MFMAs alive)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) asm volatile("" ::"v"(acc[nb]));
       return;
     }
-    if (EPI == 0 && transposed_tail && t * AS_BN >= p.n_split) {
-      // transposed columns: channel c of token `row` -> out_t[batch][c][token]; 32 consecutive tokens per lane group
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int c = t * AS_BN - p.n_split + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const unsigned short bits = (unsigned short)(pack2(acc[nb][i], 0.f) & 0xffffu);
-          __builtin_amdgcn_raw_buffer_store_b16(bits, rst, (int)(trow == kInvalid ? kInvalid : trow + (unsigned)(c * p.ldt * 2)), 0, 0);
-        }
-      return;
-    }
-    // stage the tile as bf16 (GEGLU: value * gelu(gate), 32 columns), read it back row-major, add the residual, store
     if (EPI == 1) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x2 o = {pack2(fast_gelu_mul(acc[0][4 * g], acc[1][4 * g]), fast_gelu_mul(acc[0][4 * g + 1], acc[1][4 * g + 1])),
-                         pack2(fast_gelu_mul(acc[0][4 * g + 2], acc[1][4 * g + 2]), fast_gelu_mul(acc[0][4 * g + 3], acc[1][4 * g + 3]))};
-        *reinterpret_cast<u32x2*>(stg_wr + g * 16) = o;
-      }
+      d.sv[0] = acc[0];
+      d.sv[1] = acc[1];
     } else {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x2 o = {pack2(acc[nb][4 * g], acc[nb][4 * g + 1]), pack2(acc[nb][4 * g + 2], acc[nb][4 * g + 3])};
-          *reinterpret_cast<u32x2*>(stg_wr + nb * 64 + g * 16) = o;
-        }
+        for (int g = 0; g < 4; ++g) d.pk[nb * 4 + g] = u32x2{pack2(acc[nb][4 * g], acc[nb][4 * g + 1]), pack2(acc[nb][4 * g + 2], acc[nb][4 * g + 3])};
     }
-    const int cbytes = EPI == 1 ? t * 32 * 2 : t * AS_BN * 2;
+  };
+  // epilogue_part(gi, t, d, rv): the share of slice t's epilogue that goes behind MFMA group gi of the next slice (all ten
+  // shares together issue exactly nstores(t) vector-memory stores).  Plain: groups 0-3 write the eight quads to the staging
+  // tile, groups 5-8 read a 16-byte row chunk back, add the residual and store (two roundings with a residual, as Linear -> add
+  // in the reference and as the tiled kernels).  Transposed tail (V^T): four 2-byte stores per quad, groups 0-7.  GEGLU: one
+  // quad of value * gelu(gate) per even group 0-6, the two stores behind groups 8 and 9.
+  auto epilogue_part = [&](int gi, int t, const Done& d, const u32x4 (&rv)[NST]) __attribute__((always_inline)) {
+    if (abl & 4) return;
+    if (EPI == 1) {
+      if (gi < 8 && (gi & 1) == 0) {
+        const int g = gi >> 1;
+        const u32x2 o = {pack2(fast_gelu_mul(d.sv[0][4 * g], d.sv[1][4 * g]), fast_gelu_mul(d.sv[0][4 * g + 1], d.sv[1][4 * g + 1])),
+                         pack2(fast_gelu_mul(d.sv[0][4 * g + 2], d.sv[1][4 * g + 2]), fast_gelu_mul(d.sv[0][4 * g + 3], d.sv[1][4 * g + 3]))};
+        *reinterpret_cast<u32x2*>(stg_wr + g * 16) = o;
+      }
+    } else if (transposed_tail && t * AS_BN >= p.n_split) {
+      if (gi < 8) {
+        const int nb = gi >> 2, g = gi & 3;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
+        for (int j = 0; j < 4; ++j) {
+          const int c = t * AS_BN - p.n_split + nb * 32 + 8 * g + 4 * h + j;
+          const unsigned w32 = (j & 2) ? d.pk[gi].y : d.pk[gi].x;
+          const unsigned short bits = (unsigned short)((j & 1) ? (w32 >> 16) : (w32 & 0xffffu));
+          __builtin_amdgcn_raw_buffer_store_b16(bits, rst, (int)(trow == kInvalid ? kInvalid : trow + (unsigned)(c * p.ldt * 2)), 0, 0);
+        }
+      }
+      return;
+    } else if (gi < 4) {
+#pragma unroll
+      for (int q = 2 * gi; q < 2 * gi + 2; ++q) *reinterpret_cast<u32x2*>(stg_wr + (q >> 2) * 64 + (q & 3) * 16) = d.pk[q];
+    }
+    const int i = EPI == 1 ? gi - 8 : gi - 5;
+    if (i >= 0 && i < NST) {
+      const int cbytes = EPI == 1 ? t * 32 * 2 : t * AS_BN * 2;
       const u32x2 lo = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH), hi = *reinterpret_cast<const u32x2*>(stg_rd + i * RPI * SPITCH + 8);
       u32x4 o = {lo.x, lo.y, hi.x, hi.y};
       if (RES) {
-        // (the product was rounded to bf16 by the staging: two roundings, as Linear -> add in the reference and as the tiled kernels)
         float a[8], r8[8];
         unpack8(__builtin_bit_cast(uint4, o), a);
         unpack8(__builtin_bit_cast(uint4, rv[i]), r8);
@@ -319,39 +356,81 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   // (With a LayerNorm its gamma / beta loads -- younger than both DMAs -- were already waited for, which implies the same.)
   wait_vm_dyn(ndma);
   int issued = 0;
-  int mark[AS_RING] = {-64, 0, 0};
+  // marks of the slices of this step, the next one and the one after (shifted at the end of every step: no dynamic indexing)
+  int mark0 = -64, mark1 = 0, mark2 = 0;
   auto wait_slice = [&](int step) __attribute__((always_inline)) {
-    if (step > 0) wait_vm_dyn(issued - mark[step % AS_RING]);
+#ifndef SASPA_AS_NOWAIT      // (diagnostics: how long is the wait itself?  results are garbage without it)
+    if (step > 0) wait_vm_dyn(issued - mark0);
+#endif
   };
-  auto issue_dma = [&](int step) __attribute__((always_inline)) {
-    dma_slice(step);
-    issued += ndma;
-    mark[step % AS_RING] = issued;
-  };
-
-  // One phase per step, every wave the same: (residual loads,) DMA of the slice after next, MFMAs, epilogue.  The residual
-  // loads go first: consumed after the MFMAs, the compiler's own wait for them then leaves the DMA in flight.
-  // (Built and dropped: two wave groups half a step apart -- waves 0-3 in a slice's MFMAs while their SIMD partners 4-7 run the
-  // previous slice's epilogue, two barriers per step.  Bit-identical, and slower: the GEGLU projection level with the
-  // wave-specialised kernel (189 vs 189 us on its box) instead of 3-20 % ahead of it as this loop is on five boxes
-  // (profiles/r3_as_bench.txt); the extra barrier and the half-empty phases cost more than the matrix | VALU overlap returns.)
-  for (int step = 0; step < nslices; ++step) {
-    const int t = slice_of(step);
-    wait_slice(step);
-    // publishes slice t to the other waves; also: every wave is done reading slice t-1, the slot the DMA below overwrites
-    if (!(abl & 16)) __builtin_amdgcn_s_barrier();
-    u32x4 rv[NST];
+  auto load_res = [&](int t, u32x4 (&rv)[NST]) __attribute__((always_inline)) {
     if (RES) {
 #pragma unroll
       for (int i = 0; i < NST; ++i) rv[i] = buf_load(rsr, sr_off[i] == kInvalid ? kInvalid : sr_off[i] + t * AS_BN * 2, 0);
       issued += NST;
     }
-    issue_dma(step + 2);
-    f32x16 acc[2];
-    mma(step, acc);
-    epilogue(t, acc, rv);
-    issued += nstores(t);
+  };
+
+  // One barrier per step, every wave the same program.  (Built and dropped: two wave groups half a step apart -- waves 0-3 in a
+  // slice's MFMAs while their SIMD partners 4-7 run the previous slice's epilogue, two barriers per step.  Bit-identical, and
+  // slower: the extra barrier and the half-empty phases cost more than the overlap returned; profiles/r3_as_bench.txt.)
+  // the second-dispatched half of the workgroup loses every VALU arbitration against its SIMD partners by age (it arrived
+  // 1 000-1 700 cycles late at every barrier, tools/as_stamps.py): static priority for it, no per-phase flips
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  f32x16 acc[2];
+  Done done;
+  u32x4 rv[NST] = {};
+  // step 0: nothing to finish yet
+  if (!(abl & 16)) __builtin_amdgcn_s_barrier();      // publishes slice 0 (the wait above covered this wave's share)
+  dma_slice(2);
+  issued += ndma;
+  mark2 = issued;
+  mma(0, acc, [](int) {});
+  finish(acc, done);
+  mark0 = mark1;
+  mark1 = mark2;
+  for (int step = 1; step < nslices; ++step) {
+    const int tp = slice_of(step - 1);
+    AS_STAMP(step, 0);
+    wait_slice(step);
+    AS_STAMP(step, 1);
+    // publishes this step's slice to the other waves; also: every wave is done reading the previous one, whose ring slot the
+    // DMA below overwrites
+    if (!(abl & 16)) __builtin_amdgcn_s_barrier();
+    AS_STAMP(step, 2);
+    load_res(tp, rv);                   // first: consumed behind MFMA groups 5-8, the compiler's own wait leaves the DMA in flight
+    AS_STAMP(step, 3);
+    // the slice after next: one DMA piece behind each of the first MFMA groups (a piece costs 100-200 issue cycles: six of them
+    // at the top of the step kept the matrix pipe idle for 600-1 200 cycles).  The residual loads above stay older than every
+    // piece; the previous slice's stores are issued from group 5 on (after the last piece), except the transposed tail's
+    mma(step, acc, [&](int gi) __attribute__((always_inline)) {
+      if (gi <= AS_NDMA) dma_piece(step + 2, gi);
+      epilogue_part(gi, tp, done, rv);
+    });
+    // bookkeeping in issue order: a transposed slice's 2-byte stores (four per group from group 0) interleave with the pieces,
+    // so those of the groups before the last piece (group ndma - 1) are OLDER than it; every other kind of slice stores from
+    // group 5 on, after the last piece
+    {
+      const bool tr = EPI == 0 && transposed_tail && tp * AS_BN >= p.n_split;
+      const int older = tr ? 4 * (ndma - 1) : 0;
+      issued += ndma + older;
+      mark2 = issued;
+      issued += nstores(tp) - older;
+    }
+    finish(acc, done);
+    mark0 = mark1;
+    mark1 = mark2;
   }
+  {
+    const int tl = slice_of(nslices - 1);
+    load_res(tl, rv);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) epilogue_part(gi, tl, done, rv);
+  }
+#ifdef SASPA_AS_STAMPS
+  if (stamping)
+    for (int i = 0; i < 160; ++i) (reinterpret_cast<unsigned long long*>(p.workspace) + (threadIdx.x ? 4096 : 0))[i] = stamps[i];
+#endif
 }
 
 }  // namespace

@@ -451,7 +451,8 @@ bool saspa_gemm_as_ok(const SaspaGemmParams& p) {
   } else {
     if (p.ldo % 8 || (p.residual && (p.ldr % 8 || (long long)p.M * p.ldr * 2 >= 0x7fffffffLL))) return false;
     if (p.out_t && (p.n_split % AS_BN || p.n_split < 0 || p.n_split > p.N || p.rows_per_batch <= 0 || p.rows_per_batch % 32 ||
-                    p.M % p.rows_per_batch))
+                    p.M % p.rows_per_batch || p.ldt < p.rows_per_batch ||
+                    ((long long)(p.M / p.rows_per_batch - 1) * p.st + (long long)(p.N - p.n_split) * p.ldt) * 2 >= 0x7fffffffLL))   // 32-bit buffer offsets
       return false;
   }
   if (!aligned16(p.a0) || !aligned16(p.w) || !aligned16(p.out) || (p.bias && !aligned16(p.bias)) || (p.residual && !aligned16(p.residual)) || (p.ln_gamma && (!p.ln_beta || (reinterpret_cast<uintptr_t>(p.ln_gamma) & 15u) ||

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(HERE, "..", "saspa-aug_amd")
 VARIANTS = (("full", 0), ("no W fragment reads", 1), ("no MFMA", 2), ("no epilogue", 4), ("no DMA", 8), ("no barrier", 16),
             ("DMA + barriers only", 7), ("reads + MFMA (no epilogue, no DMA)", 12), ("epilogue only", 11),
-            ("nothing but the A load + barriers", 15))
+            ("nothing but the A load + barriers", 15), ("stores out of range (issued, no bytes move)", 32))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     cs = os.path.join(PKG, "csrc")
     objs = [os.path.join(cs, f) for f in sorted(os.listdir(cs)) if f.endswith(".o") and not f.endswith(".abl.o") and f != "saspa_gemm_as.o"]

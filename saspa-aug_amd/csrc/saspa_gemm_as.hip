@@ -8,12 +8,13 @@
 //   * A is read from HBM exactly once, by the lanes that use it, in MFMA operand layout (no LDS round trip);
 //   * LayerNorm (SaspaGemmParams.ln_gamma) is applied to those registers in place: a row lives in two lanes, so the statistics
 //     are 160 in-lane adds and one cross-lane swap;
-//   * W streams through a 3-slot LDS ring in slices of 64 output columns (LDS-DMA, 41 KB per slice), shared by the 8 waves of
+//   * W streams through a 3-slot LDS ring in slices of 64 output columns (LDS-DMA, 40 KB + 64 biases per slice), shared by the 8 waves of
 //     the workgroup: one barrier per slice, the next-but-one slice in flight;
 //   * the product is taken transposed (W K^T-style: D = W_slice X^T, v_mfma_f32_32x32x16_bf16), so a lane ends up with 4
-//     consecutive output columns of ONE row per accumulator quad: bias is the accumulators' initial value, the store is 8
-//     bytes per quad, and the V^T operand of the attention kernel is a 2-byte-per-lane store with 32 consecutive tokens per
-//     channel (SaspaGemmParams.out_t) -- Q | K | V^T leave one launch.
+//     consecutive output columns of ONE row per accumulator quad: bias is the accumulators' initial value, the tile goes
+//     through a wave-private LDS tile to 16-byte row-major stores, and the V^T operand of the attention kernel is a
+//     2-byte-per-lane store with 32 consecutive tokens per channel (SaspaGemmParams.out_t) -- Q | K | V^T leave one launch;
+//   * the epilogue of slice t-1 and the DMA of slice t+2 are dealt between the MFMA groups of slice t (one wave, two streams).
 // Roofline of a slice per workgroup: 320 MFMAs (8 waves x 40) = 2 560 cycles of every SIMD's matrix pipe.  Measured with in-kernel
 // stamps (tools/as_stamps.py): a step takes 5 150 cycles on the plain layers and 6 470 with the GELU -- the MFMA groups with the
 // previous slice's epilogue and the next-but-one slice's DMA pieces dealt between them take 4 200-4 500 (each vector-memory
@@ -110,14 +111,14 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
 #pragma unroll
   for (int s = 0; s < AS_KS; ++s) af[s] = buf_load(rsa, aoff, s * 32);
 
-  // ---- W slices: slot q = 64 j + lane of slice -> W row q / 41 of the slice, 16-byte chunk q % 41 (chunk 40 = pad) ----
+  // ---- W slices: LDS chunk q = 64 j + lane of a slice <- W row q / 40 of the slice, 16-byte chunk (q % 40) ^ ((row >> 1) & 7) ----
   const rsrc_t rsw = make_rsrc(p.w);
   const rsrc_t rsb = make_rsrc(p.bias);
   const bool has_bias = p.bias != nullptr;
   const int nslices = p.N / AS_BN;
-  // Every workgroup walks the slices in a rotated order (its own starting slice): all 256 workgroups fetching the SAME 41 KB
-  // of W in the same microsecond piles onto the few L2 channels that hold it (tools/as_ablate.py: the DMA cost 2.2 us per
-  // slice that way).  Workgroups of one XCD (blockIdx = xcd + 8 k) get consecutive starts.
+  // Every workgroup walks the slices in a rotated order (its own starting slice; workgroups of one XCD -- blockIdx = xcd + 8 k --
+  // get consecutive starts), so that the 256 workgroups do not all ask the L2 for the same 40 KB in the same microsecond.
+  // (Measured neutral on its own -- the DMA alone runs at 10.8 TB/s either way, tools/as_ablate.py -- kept: it costs nothing.)
   const int rot = (int)((blockIdx.x >> 3) % (unsigned)nslices);
   auto slice_of = [&](int i) __attribute__((always_inline)) -> int {      // i-th slice this workgroup processes
     const int u = i + rot;

@@ -67,7 +67,7 @@ def test_not_eligible_falls_back_or_refuses(dev):
         ops.linear(x, w, b, ln=(g, be, 1e-5))               # a fused LayerNorm needs the kernel
 
 
-@pytest.mark.parametrize("m,n", [(49152, 2560), (65536, 1280)])
+@pytest.mark.parametrize("m,n", [(49152, 2560), (65536, 1280), (49152, 1024)])      # 1024: the 128-column GEGLU packing
 def test_geglu(dev, m, n):
     g = torch.Generator().manual_seed(n)
     x = torch.randn(m, K, generator=g).to(dev, BF)
@@ -128,3 +128,16 @@ def test_qkv_one_launch(dev):
         d = (got.float() - ref.float()).abs()
         scale = ref.float().abs().max().item()
         assert d.max().item() <= 2 ** -6 * scale and (d > 0).float().mean().item() < 2e-2, (d.max().item(), (d > 0).float().mean().item())
+
+
+def test_eligibility_levels(dev):
+    """saspa_gemm_as_eligible: 0 = cannot, 1 = can but the last round of row blocks is ragged, 2 = whole rounds."""
+    w = torch.zeros(320, K, device=dev, dtype=BF)
+    mk = lambda m: torch.zeros(m, K, device=dev, dtype=BF)
+    assert ops.linear_ln_fusable(mk(65536), w) == 2            # 256 blocks: one whole round
+    assert ops.linear_ln_fusable(mk(90112), w) == 1            # 352 blocks: 512x704
+    assert ops.linear_ln_fusable(mk(131072), w) == 2           # 512 blocks
+    assert ops.linear_ln_fusable(mk(16384), w) == 0            # 64 blocks: cannot fill the chip
+    assert ops.linear_ln_fusable(mk(65536).float(), w) == 0    # bf16 only
+    assert ops.linear_ln_fusable(torch.zeros(65536, 640, device=dev, dtype=BF), torch.zeros(320, 640, device=dev, dtype=BF)) == 0   # K = 320 only
+    assert ops.linear_ln_fusable(mk(65536), torch.zeros(328, K, device=dev, dtype=BF)) == 0                                       # N % 64

@@ -179,6 +179,10 @@ typedef struct SaspaAttnParams {
  * log2-domain logit, `scale` is ignored, and the kernel runs the loop with no per-score multiply / subtract / max
  * (saspa_attn.hip, "v2").  Same result up to the rounding point of the scale. */
 #define SASPA_ATTN_QPRESCALED 1
+/* ABI 14: `vt` holds V ROW-MAJOR -- V[b][key][heads * D], row pitch ldvt >= heads * D, batch stride svb -- i.e. the columns of
+ * a fused Q | K | V projection as they are; the kernel transposes on the way from LDS to the MFMA (ds_read_b64_tr_b16), so
+ * no transposed value projection is launched (BasicTransformerBlock.attn1 at the 32x32 / 16x16 levels). */
+#define SASPA_ATTN_V_ROWMAJOR 2
 int saspa_flash_attn_bf16(const SaspaAttnParams* p, void* stream);
 
 /* row softmax in place over a [rows][ld] matrix (unfused attention path: fp32

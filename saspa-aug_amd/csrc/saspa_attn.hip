@@ -22,7 +22,25 @@
 
 namespace {
 
-template <int KS, int NB, bool ONES, int KT>
+// ---- V ROW-MAJOR (SASPA_ATTN_V_ROWMAJOR, ABI 14) ------------------------------------------------------------------
+// The PV product wants, per lane, 8 consecutive keys of ONE channel (the A operand of O^T += V^T P^T) -- which is why V was
+// only ever materialised transposed, by a separate projection launch.  gfx950's ds_read_b64_tr_b16 delivers exactly that
+// from a ROW-MAJOR [key][d] LDS tile: per group of 16 lanes it reads a block of 4 rows x 16 columns and hands lane i column
+// i of the 4 rows.  So V can stay what the fused Q | K | V projection writes ([tokens][C] row-major) and the V^T launches of
+// the 32x32 / 16x16 levels disappear.  Lane 4 q + p of a group supplies the address of (row q, columns 4 p .. 4 p + 3).
+// LDS row pitch: a 32-lane half touches 4 rows x 16 banks (two groups 32 bytes apart x four 8-byte pieces), so the rows must
+// sit 16 or 48 banks apart (mod 64): 64 B for 32 columns, 192 B for 64 / 96, 320 B for 128 / 160.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* ptr) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr)));
+}
+constexpr int rm_pitch(int dv) {
+  int b = dv * 2;
+  while ((b / 4) % 64 != 16 && (b / 4) % 64 != 48) b += 64;
+  return b;
+}
+
+template <int KS, int NB, bool ONES, int KT, bool RM = false>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p) {
   // KT = keys per K/V tile (64 or 128): a larger tile halves the barriers / waits / staging bursts per key
   constexpr int NKB = KT / 32;               // 32-key blocks of S^T per tile
@@ -33,10 +51,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
   constexpr int KCH = 2 * KS;                // chunks per K row that are written
   constexpr int DV = NB * 32;
   constexpr int VROW = KT * 2 + 8;           // bytes; (VROW/8) odd -> conflict-free ds_read_b64
+  constexpr int RROW = rm_pitch(DV);         // RM: bytes per key row of the row-major V tile
+  constexpr int DCH = DV / 8;                // RM: 16-byte chunks per key row
   constexpr int K_BYTES = KT * KSLOTS * 16;
-  constexpr int V_BYTES = DV * VROW;
+  constexpr int V_BYTES = RM ? KT * RROW : DV * VROW;
   constexpr int NCH_K = (KT * KCH + 255) / 256;
-  constexpr int NCH_V = (DV * VCH + 255) / 256;
+  constexpr int NCH_V = RM ? (KT * DCH + 255) / 256 : (DV * VCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
   unsigned char* ksm = smem;
   unsigned char* vsm = smem + K_BYTES;
@@ -61,7 +81,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
-  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  const bf16_t* VT = RM ? reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + head * D          // V[b][key][head*D + d]
+                        : reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
   bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
 
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -89,6 +110,23 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
     k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
     koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;   // pad chunks read as zeros
   }
+  if constexpr (RM) {
+    // row-major V tile: chunk ch (8 channels) of key row `key`; chunks >= D/8 never change: the ones column (denominator,
+    // when ONES: channel D = first element of chunk D/8) / zeros
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      const int q = tid + 256 * i;
+      const int key = q / DCH, ch = q - key * DCH;
+      v_d[i] = ch;
+      v_kc[i] = key;                         // (RM: the tile row = key)
+      v_lds[i] = (q < KT * DCH && ch < D8) ? key * RROW + ch * 16 : -1;
+      voff[i] = (q < KT * DCH && ch < D8) ? (unsigned)(key * p.ldvt * 2 + ch * 16) : kInv;
+    }
+    for (int q = tid; q < KT * DCH; q += 256) {
+      const int key = q / DCH, ch = q - key * DCH;
+      if (ch >= D8) *reinterpret_cast<u32x4*>(vsm + key * RROW + ch * 16) = u32x4{(ONES && ch == D8) ? 0x00003F80u : 0u, 0u, 0u, 0u};
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < NCH_V; ++i) {
     const int q = tid + 256 * i;
@@ -108,7 +146,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
       dst[1] = u32x2{fill, fill};
     }
   }
+  }
   u32x4 kreg[NCH_K], vreg[NCH_V];
+  // RM: this lane's address inside a 4-key x 16-channel block of the transposed read (group g = lane >> 4: channels
+  // 16 (g & 1) .., keys 4 (g >> 1) ..; lane 4 q + p of the group: key q, channels 4 p ..)
+  const int tr_base = (4 * (lane >> 5) + ((lane & 15) >> 2)) * RROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
   auto load_tile = [&](int key0) __attribute__((always_inline)) {
     const bool tail = key0 + KT > p.nk;                  // wave-uniform
@@ -122,8 +164,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
       unsigned o = voff[i];
-      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+      if (RM) {
+        if (tail && key0 + v_kc[i] >= p.nk) o = kInv;                    // key rows >= nk: zeros
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)(key0 * p.ldvt * 2), 0));
+      } else {
+        if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+      }
     }
   };
   auto store_tile = [&](int key0) __attribute__((always_inline)) {
@@ -133,6 +180,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
       if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
+      if (RM) {
+        if (v_lds[i] >= 0) *reinterpret_cast<u32x4*>(vsm + v_lds[i]) = vreg[i];
+        continue;
+      }
       if (v_lds[i] >= 0) {
         u32x4 v = vreg[i];
         if (tail) {
@@ -231,9 +282,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const SaspaAttnParams p
       const int koff = (kb * 32 + 16 * half + 4 * h) * 2;  // bytes
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + koff;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+        u32x2 lo, hi;
+        if (RM) {
+          // keys 16 ks + 4 h + (0..3) and + 8, channel 32 nb + r: two transposed reads of the row-major tile
+          const unsigned char* blk = vsm + tr_base + (kb * 32 + 16 * half) * RROW + nb * 64;
+          lo = lds_read_tr16(blk);
+          hi = lds_read_tr16(blk + 8 * RROW);
+        } else {
+          const unsigned char* vrow = vsm + (nb * 32 + r) * VROW + koff;
+          lo = *reinterpret_cast<const u32x2*>(vrow);
+          hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+        }
         const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
         acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
                                                             __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
@@ -570,8 +629,9 @@ __global__ __launch_bounds__(256) void flash_attn_v2_kernel(const SaspaAttnParam
 // ABL (diagnostics, `make ABLATION=1` + SASPA_ATTN_ABLATE only; 0 in the shipped library): 1 no exponentials, 2 no MFMAs,
 // 4 no LDS fragment reads, 8 no staging (global loads / LDS stores / barriers), 16 stamps (s_memtime / s_memrealtime of
 // the tile loop of every workgroup's thread 0 behind the output tensor: tools/attn_ablate.py)
-template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0>
+template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0, bool RM = false>
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAttnParams p) {
+  // RM: V row-major, read through ds_read_b64_tr_b16 (see lds_read_tr16 at the top of the file)
   // NW waves of 32 queries per workgroup: 8 waves halve the K / V^T bytes every query block pulls through L1 / LDS
   // (the staging is the largest single cost of the loop: tools/attn_ablate.py, profiles/r3_attn_ablation.txt)
   constexpr int NT = 64 * NW;
@@ -580,11 +640,12 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
   constexpr int KCH = 2 * KS;
   constexpr int DV = NB * 32;
   constexpr int VROW = KT * 2 + 16;            // 144 B = 9 slots of 16 B (odd): conflict-free ds_read_b128
+  constexpr int RROW = rm_pitch(DV), DCH = DV / 8;
   constexpr int K_BYTES = KT * KSLOTS * 16;
-  constexpr int V_BYTES = DV * VROW;
+  constexpr int V_BYTES = RM ? KT * RROW : DV * VROW;
   constexpr int BUF = K_BYTES + V_BYTES;
   constexpr int NCH_K = (KT * KCH + NT - 1) / NT;
-  constexpr int NCH_V = (DV * VCH + NT - 1) / NT;
+  constexpr int NCH_V = RM ? (KT * DCH + NT - 1) / NT : (DV * VCH + NT - 1) / NT;
   constexpr float BIAS = 8.0f;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BUF];
 
@@ -604,7 +665,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
 
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
-  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  const bf16_t* VT = RM ? reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + head * D
+                        : reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
   bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
 
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -628,6 +690,24 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
     k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
     koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;
   }
+  if constexpr (RM) {
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      const int q = tid + NT * i;
+      const int key = q / DCH, ch = q - key * DCH;
+      v_kc[i] = key;                         // (RM: the tile row = key)
+      v_lds[i] = (q < KT * DCH && ch < D8) ? key * RROW + ch * 16 : -1;
+      voff[i] = (q < KT * DCH && ch < D8) ? (unsigned)(key * p.ldvt * 2 + ch * 16) : kInv;
+    }
+    for (int q = tid; q < KT * DCH; q += NT) {
+      const int key = q / DCH, ch = q - key * DCH;
+      if (ch >= D8) {
+#pragma unroll
+        for (int bf = 0; bf < 4; ++bf)
+          *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + key * RROW + ch * 16) = u32x4{(ONES && ch == D8) ? 0x00003F80u : 0u, 0u, 0u, 0u};
+      }
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < NCH_V; ++i) {
     const int q = tid + NT * i;
@@ -645,6 +725,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
         *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + d * VROW + kc * 16) = u32x4{fill, fill, fill, fill};
     }
   }
+  }
+  const int tr_base = (4 * (lane >> 5) + ((lane & 15) >> 2)) * RROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   // two staging register sets: tile t+4 is requested at step t and written to LDS at step t+2 (one step of
   // flight time is less than the L2 latency under load)
   u32x4 kregA[NCH_K], vregA[NCH_V], kregB[NCH_K], vregB[NCH_V];
@@ -660,8 +742,13 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
       unsigned o = voff[i];
-      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+      if (RM) {
+        if (tail && key0 + v_kc[i] >= p.nk) o = kInv;                    // key rows >= nk: zeros
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)(key0 * p.ldvt * 2), 0));
+      } else {
+        if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+      }
     }
   };
   auto store_tile = [&](int key0, unsigned char* buf, const u32x4 (&kreg)[NCH_K], const u32x4 (&vreg)[NCH_V]) __attribute__((always_inline)) {
@@ -673,6 +760,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
       if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < NCH_V; ++i) {
+      if (RM) {
+        if (v_lds[i] >= 0) *reinterpret_cast<u32x4*>(vsm + v_lds[i]) = vreg[i];
+        continue;
+      }
       if (v_lds[i] >= 0) {
         u32x4 v = vreg[i];
         if (tail) {
@@ -734,7 +825,14 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
       const u32x4 pf = {P[kb][4 * half + 0], P[kb][4 * half + 1], P[kb][4 * half + 2], P[kb][4 * half + 3]};
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const u32x4 vf = *reinterpret_cast<const u32x4*>(vsm + (nb * 32 + r) * VROW + ks * 32 + 16 * h);
+        u32x4 vf;
+        if (RM) {
+          const unsigned char* blk = vsm + tr_base + ks * 16 * RROW + nb * 64;
+          const u32x2 lo = lds_read_tr16(blk), hi = lds_read_tr16(blk + 8 * RROW);
+          vf = u32x4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+          vf = *reinterpret_cast<const u32x4*>(vsm + (nb * 32 + r) * VROW + ks * 32 + 16 * h);
+        }
         acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
       }
     }
@@ -771,7 +869,14 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
       const unsigned char* ksm = smem + ((t + 1) & 3) * BUF;
       auto frag = [&](int i) __attribute__((always_inline)) -> u32x4 {
         if (ABL & 4) return u32x4{(unsigned)i, 0x3f803f80u, (unsigned)lane, 0x3f803f80u};
-        if (i < NPV) return *reinterpret_cast<const u32x4*>(vsm + ((i % NB) * 32 + r) * VROW + (i / NB) * 32 + 16 * h);
+        if (i < NPV) {
+          if (RM) {
+            const unsigned char* blk = vsm + tr_base + (i / NB) * 16 * RROW + (i % NB) * 64;
+            const u32x2 lo = lds_read_tr16(blk), hi = lds_read_tr16(blk + 8 * RROW);
+            return u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+          return *reinterpret_cast<const u32x4*>(vsm + ((i % NB) * 32 + r) * VROW + (i / NB) * 32 + 16 * h);
+        }
         const int q = i - NPV, kb = q / KS, sx = q - kb * KS;
         return *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * sx + h) * 16);
       };
@@ -922,6 +1027,7 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
   //   with two buffers and one barrier per tile.  3 / 4: the software-pipelined v3 loop (8 waves = 256 queries per workgroup).
   const char* me = getenv("SASPA_ATTN_MODE");
   int mode = me ? atoi(me) : -1;
+  const bool rm = (p.flags & SASPA_ATTN_V_ROWMAJOR) != 0;
   if (p.flags & SASPA_ATTN_QPRESCALED) {
     // v2 / v3 keep S' and the packed P live together, which fits two waves per SIMD up to d = 96 (v3 at d = 96 only with
     // the spare ones row); wider heads (SD-1.5's 16x16 / 8x8 levels, d = 160) and short key sequences (cross-attention:
@@ -936,6 +1042,7 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
       mode = (V3_OK && !p.causal && wg8 >= 512) ? 4 : 2;
     }
     if ((mode == 3 || mode == 4) && (!V3_OK || p.causal)) mode = 2;
+    if (rm && mode != 3 && mode != 4) mode = 0;       // row-major V exists on the v1 and v3 loops
     if (mode == 0 || !V2_OK || !big) {
       p.scale = 0.6931471805599453f;       // the v1 loop multiplies by log2(e): net factor 1
     } else if constexpr (V2_OK) {
@@ -955,8 +1062,13 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
 #undef SASPA_V3A
           }
 #endif
-          if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8>), grid8, dim3(512), 0, s, p);
-          else hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, false, 8>), grid8, dim3(512), 0, s, p);
+          if (rm) {
+            if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8, 0, true>), grid8, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, false, 8, 0, true>), grid8, dim3(512), 0, s, p);
+          } else {
+            if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8>), grid8, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, false, 8>), grid8, dim3(512), 0, s, p);
+          }
           SASPA_CHECK_LAUNCH();
           return 0;
         }
@@ -969,7 +1081,10 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
       return 0;
     }
   }
-  if (p.D < 32 * NB) {
+  if (rm) {        // (64-key tiles: the row-major tile of 128 keys x 320 bytes would not leave two workgroups per CU at d = 160)
+    if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, false, 64, true>), grid, dim3(256), 0, s, p);
+  } else if (p.D < 32 * NB) {
     if (big) hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, BIG_OK ? 128 : 64>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((flash_attn_kernel<KS, NB, true, 64>), grid, dim3(256), 0, s, p);
   } else {
@@ -1017,9 +1132,14 @@ extern "C" int saspa_flash_attn_bf16(const SaspaAttnParams* pp, void* stream) {
   if (p.D % 8 || p.D > 160) return SASPA_ERANGE;
   if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4 || p.sqb % 8 || p.skb % 8 || p.svb % 8 || p.sob % 4) return SASPA_EALIGN;
   if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.vt) || !aligned16(p.o)) return SASPA_EALIGN;
-  if (p.ldvt < ((p.nk + 7) / 8) * 8) return SASPA_ERANGE;
+  if (p.flags & ~(SASPA_ATTN_QPRESCALED | SASPA_ATTN_V_ROWMAJOR)) return SASPA_EINVAL;
+  if (p.flags & SASPA_ATTN_V_ROWMAJOR) {       // vt is V[b][key][heads * D] (row pitch ldvt)
+    if (p.ldvt < p.heads * p.D || (long long)p.nk * p.ldvt * 2 >= (1ll << 31)) return SASPA_ERANGE;
+  } else {
+    if (p.ldvt < ((p.nk + 7) / 8) * 8 || (long long)p.D * p.ldvt * 2 >= (1ll << 31)) return SASPA_ERANGE;
+  }
   if (p.ldq < p.heads * p.D || p.ldk < p.heads * p.D || p.ldo < p.heads * p.D) return SASPA_ERANGE;
-  if ((long long)p.nk * p.ldk * 2 >= (1ll << 31) || (long long)p.D * p.ldvt * 2 >= (1ll << 31)) return SASPA_ERANGE;
+  if ((long long)p.nk * p.ldk * 2 >= (1ll << 31)) return SASPA_ERANGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int D = p.D;
   if (D <= 16) return launch_attn<1, 1>(p, s);

@@ -114,20 +114,26 @@ def project_vt(x, wv, nk):
 ATTN_LOG2E = 1.4426950408889634
 
 
-def attention_core(q, k, vt, heads, nq, nk, causal=False, prescaled=False):
-    """q: [B,nq,C] view, k: [B,nk,C] view, vt: [B,C,ld].  bf16 with head dim <= 160: fused
+def rowmajor_v_enabled():
+    """SASPA_ATTN_VROW=0: self-attention goes back to the separate transposed value projection (A/B knob)."""
+    import os
+    return os.environ.get("SASPA_ATTN_VROW", "1") != "0"
+
+
+def attention_core(q, k, vt, heads, nq, nk, causal=False, prescaled=False, v_rowmajor=False):
+    """q: [B,nq,C] view, k: [B,nk,C] view, vt: [B,C,ld] (v_rowmajor: V itself, [B,nk,C] view).  bf16 with head dim <= 160: fused
     flash kernel; otherwise (fp32 parity mode, 512-wide VAE head): scores GEMM -> row softmax
     -> PV GEMM, all batched over (batch, head).
     prescaled: q was projected with head_dim^-0.5 * log2(e) folded into its weights (_Packed.attn(qscale=...));
     only the flash path takes such queries."""
     b = q.shape[0]
-    c = vt.shape[1]
+    c = vt.shape[2] if v_rowmajor else vt.shape[1]
     d = c // heads
     out = torch.empty((b, nq, c), device=q.device, dtype=q.dtype)
     scale = d ** -0.5
     if q.dtype == torch.bfloat16 and d <= 160:
-        return ops.flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal, prescaled=prescaled)
-    assert not prescaled, "prescaled queries exist for the flash path only"
+        return ops.flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal, prescaled=prescaled, v_rowmajor=v_rowmajor)
+    assert not prescaled and not v_rowmajor, "prescaled queries / row-major V exist for the flash path only"
     lds = ops.round8(nk)
     assert vt.stride(1) >= lds
     scores = torch.empty((b, heads, nq, lds), device=q.device, dtype=q.dtype)
@@ -191,9 +197,10 @@ class _Net:
             pk.attn(t + ".attn2", False, qscale=qs)
             if qs is not None:
                 self.qscaled[t] = qs
-            if self.dtype == torch.bfloat16 and c == 320 and (t + ".attn1.qk.b") not in self.p:
-                # level-0 blocks: [to_q; to_k; to_v] in one matrix for the A-stationary kernel (LayerNorm fused, V^T written
-                # transposed by the same launch: ops.linear(ln=, out_t=)); the separate matrices stay for the other sizes
+            if self.dtype == torch.bfloat16 and c // heads <= 160 and (t + ".attn1.qk.b") not in self.p:
+                # [to_q; to_k; to_v] in one matrix: at level 0 for the A-stationary kernel (LayerNorm fused, V^T written
+                # transposed by the same launch: ops.linear(ln=, out_t=)), elsewhere for ONE projection launch whose V
+                # columns the flash kernel reads row-major (SASPA_ATTN_V_ROWMAJOR) -- no transposed value projection
                 self.p[t + ".attn1.qkv.w"] = torch.cat([self.p[t + ".attn1.qk.w"], self.p[t + ".attn1.v.w"][:, :c]], 0).contiguous()
             packed = W.pack_geglu(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"]) \
                 if self.dtype == torch.bfloat16 else None
@@ -342,16 +349,23 @@ class _Net:
             # self-attention.  Level 0 of a full-size batch: LayerNorm + Q | K + V^T in ONE launch of the A-stationary kernel
             # (saspa_gemm_as.hip) instead of three launches that each re-read the tokens
             wqkv = p.get(t + ".attn1.qkv.w")
-            fuse = wqkv is not None and t not in self.fp8_blocks and n % 32 == 0 and ops.linear_ln_fusable(h, wqkv, n_out=2 * c)
+            fuse = wqkv is not None and c == 320 and t not in self.fp8_blocks and n % 32 == 0 and \
+                ops.linear_ln_fusable(h, wqkv, n_out=2 * c)
+            pre = t in self.qscaled
             if fuse:
                 vt = torch.empty((b, c, n), device=h.device, dtype=h.dtype)
                 qk = ops.linear(h, wqkv, None, ln=(p[t + ".norm1.g"], p[t + ".norm1.b"], 1e-5), out_t=vt, n_split=2 * c, rows_per_batch=n)
+                o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
+            elif wqkv is not None and rowmajor_v_enabled():
+                # one projection launch; the attention kernel takes its V columns as they are
+                n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
+                qkv = ops.linear(n1, wqkv)                                     # [B,N,3C]
+                o = attention_core(qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:3 * c], heads, n, n, prescaled=pre, v_rowmajor=True)
             else:
                 n1 = ops.layernorm(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
                 qk = ops.linear(n1, p[t + ".attn1.qk.w"])                     # [B,N,2C]
                 vt = project_vt(n1, p[t + ".attn1.v.w"], n)
-            pre = t in self.qscaled
-            o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
+                o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
             h = ops.linear(o, p[t + ".attn1.o.w"], p[t + ".attn1.o.b"], residual=h)
             if t in self.fp8_blocks:
                 # W8A8: LayerNorm + per-token quantisation in one pass, e4m3 x e4m3 MFMA, scales applied in the epilogue

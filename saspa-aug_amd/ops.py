@@ -318,10 +318,12 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     return out
 
 
-def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False, prescaled=False):
+def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False, prescaled=False, v_rowmajor=False):
     """q: [B, nq, >=heads*d] view, k: [B, nk, >=heads*d] view, vt: [B, heads*d, ldvt] (keys
     contiguous), out: [B, nq, >=heads*d] view.  bf16 only.  prescaled: q already carries scale * log2(e)
-    (folded into the to_q weights, weights.ATTN_LOG2E) -> SASPA_ATTN_QPRESCALED, `scale` is ignored."""
+    (folded into the to_q weights, weights.ATTN_LOG2E) -> SASPA_ATTN_QPRESCALED, `scale` is ignored.
+    v_rowmajor: `vt` is V itself, [B, nk, >=heads*d] like k (a view into a fused Q | K | V projection) ->
+    SASPA_ATTN_V_ROWMAJOR: the kernel transposes between LDS and the MFMA, no V^T projection is needed."""
     _check_dev(q, k, vt, out)
     lib = _lib.load()
     if q.dtype != torch.bfloat16:
@@ -332,7 +334,7 @@ def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False, prescaled=F
     p.vt, p.ldvt, p.svb = _ptr(vt), vt.stride(1), vt.stride(0)
     p.o, p.ldo, p.sob = _ptr(out), out.stride(1), out.stride(0)
     p.batch, p.heads, p.D, p.nq, p.nk = q.shape[0], heads, d, nq, nk
-    p.scale, p.causal, p.flags = float(scale), int(causal), (1 if prescaled else 0)
+    p.scale, p.causal, p.flags = float(scale), int(causal), (1 if prescaled else 0) | (2 if v_rowmajor else 0)
     _launch("flash_attn", 4.0 * q.shape[0] * heads * nq * nk * d,
             lambda: _lib.check(lib.saspa_flash_attn_bf16(C.byref(p), _stream()), "saspa_flash_attn_bf16"),
             (q.shape[0], heads, nq, nk, d))

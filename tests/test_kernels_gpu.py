@@ -295,6 +295,47 @@ def test_flash_attn_prescaled(dev, monkeypatch, mode, d, heads, nq, nk, causal):
     assert_close(out.float().cpu(), ref, dtype, what=f"flash prescaled d={d} nq={nq} nk={nk}")
 
 
+@pytest.mark.parametrize("d,heads,nq,nk,causal", [
+    (40, 8, 200, 200, False), (80, 4, 300, 300, False), (160, 2, 256, 256, False), (64, 3, 77, 77, True),
+    (40, 8, 130, 77, False), (8, 4, 64, 64, False), (16, 2, 33, 200, False), (32, 4, 128, 64, False), (128, 2, 96, 130, False),
+    (40, 8, 1024, 1024, False), (80, 8, 1024, 1024, False), (64, 4, 640, 1090, False), (96, 2, 512, 2048 + 31, False)])
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_flash_attn_v_rowmajor(dev, monkeypatch, d, heads, nq, nk, causal, prescaled):
+    """SASPA_ATTN_V_ROWMAJOR (ABI 14): V handed over as the V columns of a fused Q | K | V projection, transposed between LDS and the
+    MFMA by ds_read_b64_tr_b16 -- the same MFMA operands as the V^T form, so BIT-EQUAL with it on the loop that serves both (v1
+    below 512 keys or without prescaled queries; the 8-wave v3 loop for long prescaled sequences, pinned here with mode 4)."""
+    dtype = torch.bfloat16
+    bsz, c = 8, heads * d
+    monkeypatch.setenv("SASPA_ATTN_MODE", "4" if prescaled else "0")
+    qs, qeff = _prescaled_q(_rand(bsz, nq, c, seed=21), d) if prescaled else (q(_rand(bsz, nq, c, seed=21), dtype),) * 2
+    kk = q(_rand(bsz, nk, c, seed=22), dtype)
+    vv = q(_rand(bsz, nk, c, seed=23), dtype)
+    ref = _ref_attn(qeff, kk, vv, heads, causal)
+    n = max(nq, nk)
+    qkv = torch.full((bsz, n, 3 * c + 8), float("nan"), device=dev, dtype=dtype)     # a fused projection's output; pad columns unused
+    qkv[:, :nq, :c] = qs.to(dev, dtype)
+    qkv[:, :nk, c:2 * c] = kk.to(dev, dtype)
+    qkv[:, :nk, 2 * c:3 * c] = vv.to(dev, dtype)
+    ldvt = ops.round8(nk)
+    vt = torch.zeros(bsz, c, ldvt, device=dev, dtype=dtype)
+    vt[:, :, :nk] = vv.transpose(1, 2).to(dev, dtype)
+    out_t, out_r = (torch.zeros(bsz, nq, c, device=dev, dtype=dtype) for _ in range(2))
+    args = (heads, d, nq, nk, d ** -0.5, causal)
+    ops.flash_attn(qkv[:, :nq, :c], qkv[:, :nk, c:2 * c], vt, out_t, *args, prescaled=prescaled)
+    ops.flash_attn(qkv[:, :nq, :c], qkv[:, :nk, c:2 * c], qkv[:, :nk, 2 * c:3 * c], out_r, *args, prescaled=prescaled, v_rowmajor=True)
+    assert_close(out_r.float().cpu(), ref, dtype, what=f"flash row-major V d={d} nq={nq} nk={nk}")
+    if not (prescaled and nk >= 512 and d >= 96):     # (prescaled long sequences at d >= 96 take different loops in the two forms)
+        big_v3 = prescaled and nk >= 512 and not causal
+        if big_v3 or not prescaled or nk < 512:
+            same = torch.equal(out_r, out_t)
+            # the V^T form runs 128-key tiles on v1 for long sequences at d <= 96, the row-major form 64-key tiles: equal up to the
+            # tile-size-dependent rescale points only there
+            if not prescaled and nk >= 512 and d <= 96:
+                assert (out_r.float() - out_t.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+            else:
+                assert same, (out_r.float() - out_t.float()).abs().max().item()
+
+
 @pytest.mark.parametrize("mode", ["2", "4"])
 @pytest.mark.parametrize("spike,shift", [(6.0, 0.0), (60.0, 0.0), (1.0, -40.0), (6.0, 25.0)])
 def test_flash_attn_prescaled_level_moves(dev, monkeypatch, mode, spike, shift):

@@ -2,7 +2,8 @@
 SD-1.5 level 0/1/2 self- and cross-attention at CFG batch 16; SDXL levels 1/2 (head dim 64) at batch 8.
 Columns: v1 = plain queries (scale applied per score); pre0 / pre1 / pre2 = prescaled queries (SASPA_ATTN_QPRESCALED)
 through the v1 loop / the v2 loop with one LDS buffer / the v2 loop with two buffers and one barrier per tile
-(SASPA_ATTN_MODE = 0 / 1 / 2); pre4 = the software-pipelined v3 loop, 8 waves per workgroup (mode 4); auto = the shipped dispatch rule.  usage: python tools/attn_bench.py [quick] [512x704]"""
+(SASPA_ATTN_MODE = 0 / 1 / 2); pre4 = the software-pipelined v3 loop, 8 waves per workgroup (mode 4); auto = the shipped dispatch rule;
+rm = auto with V ROW-MAJOR (SASPA_ATTN_V_ROWMAJOR: the V columns of a fused Q | K | V buffer, transposed LDS reads).  usage: python tools/attn_bench.py [quick] [512x704]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
@@ -23,19 +24,24 @@ for (B, H, NQ, NK, D) in shapes:
     k = torch.randn(B, NK, C, device=dev).bfloat16()
     vt = torch.randn(B, C, ops.round8(NK), device=dev).bfloat16()
     out = torch.empty(B, NQ, C, device=dev, dtype=torch.bfloat16)
-    arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre2", qs, True, "2"), ("pre4", qs, True, "4"), ("auto", qs, True, "")]
+    qkv = torch.randn(B, NK, 3 * C, device=dev).bfloat16()
+    vrm = qkv[:, :, 2 * C:]
+    vt.copy_(vrm.transpose(1, 2)[:, :, :NK]) if vt.shape[2] == NK else vt[:, :, :NK].copy_(vrm.transpose(1, 2))
+    arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre2", qs, True, "2"), ("pre4", qs, True, "4"), ("auto", qs, True, ""),
+            ("rm", qs, True, "rm")]
     best = {a[0]: [] for a in arms}
     ref = None
     for rnd in range(ROUNDS + 1):
         for name, qq, pre, mode in arms:
-            if mode:
+            rm = mode == "rm"
+            if mode and not rm:
                 os.environ["SASPA_ATTN_MODE"] = mode
             else:
                 os.environ.pop("SASPA_ATTN_MODE", None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(REP):
-                ops.flash_attn(qq, k, vt, out, H, D, NQ, NK, D ** -0.5, prescaled=pre)
+                ops.flash_attn(qq, k, vrm if rm else vt, out, H, D, NQ, NK, D ** -0.5, prescaled=pre, v_rowmajor=rm)
             e1.record(); torch.cuda.synchronize()
             if rnd:
                 best[name].append(e0.elapsed_time(e1) * 1000 / REP)

@@ -1148,7 +1148,10 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
         // 3/4 of a wave of tiles or more: no split-K.  (144 <= t < 192 is the 512x704 / 512x768 buckets' 32x44 / 32x48 level:
         // 176 / 192 workgroups in one round against 704 / 768 4-wave tiles in two rounds of 512 slots -- 74 vs 124 us at
         // (22528, 640, 2560); t = 128, the 512x512 case, ties and stays on the 4-wave tiles)
-        if (t >= (model ? 144 : 192) && (!model || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, fn);
+        // ... unless the tiles are just over a whole number of rounds (264 / 288 tiles of the fused Q|K|V projection of the 16x22 /
+        // 16x24 level: two rounds at 52-56 %, 99 us against 81 on the 4-wave tiles): then the finer tiles below
+        const bool ragged = model && t > 256 && t * 100 < ((t + 255) / 256) * 256 * 65;
+        if (!ragged && t >= (model ? 144 : 192) && (!model || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, fn);
         // fewer wide tiles than CUs but a long K (the 3x3 convs of the 32x32 / 16x16 levels): the wide kernel on K
         // slices -- measured 1.17-1.45x the 128x160 kernel at M = 16 384 / 4 096 (tools/conv_variant_sweep.py)
         static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);   // A/B knob

@@ -129,6 +129,10 @@ def _set_splitk(p, m, n, k, t, force=None):
     return None
 
 
+def _as_over_stats():
+    return os.environ.get("SASPA_GEMM_AS_OVER_STATS", "1") != "0"
+
+
 def gn_fusion_enabled():
     """SASPA_GN_FUSE=0: every GroupNorm runs its own statistics pass (A/B knob for the epilogue statistics)."""
     return os.environ.get("SASPA_GN_FUSE", "1") != "0"
@@ -205,6 +209,12 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
     p.korder = int(getattr(w, "saspa_korder", 0)) if korder is None else int(korder)
+    # a level-0 pointwise layer the A-stationary kernel takes on whole rounds (Transformer2DModel.proj_out): that kernel has no
+    # statistics epilogue, and A-stationary + the consumer's own statistics pass (27 + 12 us) beats the tiled kernel with the
+    # statistics in its epilogue (53 us); SASPA_GEMM_AS_OVER_STATS=0 keeps the statistics
+    if gn_unit and kh == 1 and kw == 1 and c1 == 0 and x.dtype == torch.bfloat16 and _as_over_stats() and \
+            lib.saspa_gemm_as_eligible(C.byref(p)) == 2:
+        gn_unit = None
     _gs = _gn_stats_for(p, out, gn_unit, b, ho * wo, n)  # noqa: F841   (set BEFORE the split-K heuristic looks at p)
     _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),

@@ -63,16 +63,30 @@ class Recorder:
             return "batched_gemm"
         return "pointwise_linear" if kh in (0, 1) else "conv_other"
 
+    @staticmethod
+    def gemm_bytes(meta, es=2):
+        """ALGORITHMIC HBM bytes of one implicit-GEMM launch: every operand once -- the input pixels the windows cover
+        (not the im2col matrix), the weights, the output, the residual if any."""
+        m, n, k, kh, stride, up, _concat, has_res, ncols = meta
+        if kh < 0:                                   # raw batched GEMM: per batch an [M,K] and an [N,K] operand
+            nb = -kh
+            return es * nb * (m * k + n * k + m * ncols * (2 if has_res else 1))
+        taps = max(kh, 1) ** 2
+        rows_in = m * stride * stride / (4.0 if up else 1.0)
+        return es * (rows_in * (k / taps) + n * k + m * ncols * (2 if has_res else 1))
+
     def summary(self, by_class=False):
         import torch
         torch.cuda.synchronize()
         out = {}
         for kind, flops, e0, e1, meta in self.items:
             key = self.classify(kind, meta) if by_class else kind
-            d = out.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+            d = out.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += e0.elapsed_time(e1)
+            if kind == "gemm" and meta is not None and len(meta) >= 9:
+                d["bytes"] += self.gemm_bytes(meta)
         return out
 
 
@@ -88,19 +102,14 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """Oracle (torch fp32 on the usable host cores) on a BOUNDED sample of the same workload:
-    repeated UNet+ControlNet CFG evaluations of one 512x512 image (each 2.167 TFLOP incl. the
-    conditioning embedding the un-hoisted oracle recomputes) until ~seconds_budget of CPU work;
-    EXTRAPOLATED by FLOPs to one 50-step image (109.33 TFLOP).  The directly timed BASELINE configs[0] run
-    (1 image, 10 steps, whole pipeline) is `--baselines full` -> profiles/r2_bench_line_v0_with_baselines_full.json."""
+def cpu_eval_sample(seconds_budget=12.0):
+    """Cross-check figure: repeated UNet+ControlNet CFG evaluations of one 512x512 image on the oracle (each 2.167 TFLOP
+    incl. the conditioning embedding the un-hoisted oracle recomputes) for ~seconds_budget of CPU work."""
     import torch
 
     from oracle import sd_models as OM
     from saspa_aug_amd import config as CFG
     from saspa_aug_amd import weights as W
-    cores = effective_cpus()
-    torch.set_num_threads(cores)
     cf = CFG.SD15
     g = torch.Generator().manual_seed(0)
     sd_u = W.synth_state_dict("unet", cf["unet"], 0)
@@ -116,32 +125,34 @@ def cpu_baseline(seconds_budget=15.0):
             OM.unet_forward(sd_u, cf["unet"], x, 981 - 20 * n, ctx, down, mid)
             n += 1
     dt = (time.time() - t0) / n
-    sec_per_image = dt * (F_IMG_50 / step_flop)
-    return dict(value=round(1.0 / sec_per_image, 6), unit="images/s", cores=cores, kind="port", extrapolated=True,
-                sample=f"{n} UNet+ControlNet CFG evaluations (batch 2, 512x512, torch fp32 oracle), {dt:.2f} s each on "
-                       f"{cores} threads (cgroup quota; os.cpu_count()={os.cpu_count()}), EXTRAPOLATED by 109.33 TFLOP / "
-                       f"{step_flop / 1e12:.3f} TFLOP to one 50-step image",
-                cpu_tflops=round(step_flop / dt / 1e12, 3))
+    return dict(evaluations=n, seconds_each=round(dt, 3), cpu_tflops=round(step_flop / dt / 1e12, 3),
+                images_per_s_at_50_steps_extrapolated=round(1.0 / (dt * F_IMG_50 / step_flop), 6))
 
 
-def baselines_full(dev):
-    """SURVEY 8(d) comparators, `--baselines full` only (minutes of work; the result is committed under profiles/):
-      cpu_config1 : BASELINE configs[0] timed DIRECTLY -- the whole oracle pipeline (CLIP text, 10 x CFG evaluation of
-                    UNet + ControlNet, VAE decode, u8) for 1 image, 1 prompt, 512x512, on the host cores;
-      eager_port  : the same oracle modules on one MI355X through PyTorch-ROCm eager (rocBLAS / MIOpen / SDPA) under bf16
-                    autocast -- the "naive port" a maintainer gets by moving the reference's modules to the GPU -- one image
-                    per call (CFG batch 2), as the reference calls its pipeline."""
-    import numpy as np
+F_IMG_10 = 2135.06e9 * 10 + 2579.2e9     # algorithmic FLOP of BASELINE configs[0] (1 image, 10 steps)
+
+
+def cpu_baseline(sample_only=False):
+    """The CPU restatement of the reference pipeline (oracle/, torch fp32) on the host cores this process is granted.
+    Default: BASELINE configs[0] -- 1 synthetic image 512x512, 1 prompt, 10 DDIM steps, the WHOLE pipeline (CLIP text,
+    10 x CFG evaluation of UNet + ControlNet, DDIM updates, VAE decode, u8) -- TIMED DIRECTLY (about 70 s on 16 cores).
+    `value` is that measurement expressed in the metric's unit (50-step images/s): seconds x F_img(50) / F_img(10); the cost
+    of a DDIM trajectory is linear in its step count, nothing else is extrapolated.  `eval_sample` is the bounded
+    3-evaluation cross-check the earlier rounds reported (sample_only=True: only that, `extrapolated` true)."""
     import torch
-
+    cores = effective_cpus()
+    torch.set_num_threads(cores)
+    if sample_only:
+        sm = cpu_eval_sample(15.0)
+        return dict(value=sm["images_per_s_at_50_steps_extrapolated"], unit="images/s", cores=cores, kind="port", extrapolated=True,
+                    sample=f"{sm['evaluations']} UNet+ControlNet CFG evaluations (batch 2, 512x512, torch fp32 oracle), "
+                           f"{sm['seconds_each']:.2f} s each on {cores} threads, EXTRAPOLATED by FLOPs to one 50-step image",
+                    cpu_tflops=sm["cpu_tflops"])
     from oracle import pipeline as OP
-    from oracle import sd_models as OM
     from oracle.canny import generate_canny_array
     from saspa_aug_amd import config as CFG
     from saspa_aug_amd import weights as W
     from saspa_aug_amd.synthetic import negative_prompt_ids, synthetic_image, synthetic_prompt_ids
-    cores = effective_cpus()
-    torch.set_num_threads(cores)
     cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
     fam = W.synth_family(cfgs, seed=0)
     vocab = cfgs["text"]["vocab"]
@@ -149,15 +160,35 @@ def baselines_full(dev):
     neg = torch.from_numpy(negative_prompt_ids(vocab))
     ctrl = generate_canny_array(synthetic_image(512, 512, 0), 120, 200)
     lat = torch.randn((1, 4, 64, 64), generator=torch.Generator().manual_seed(1))
-    out = {}
     t0 = time.time()
     OP.sd_controlnet_pipeline(fam, cfgs, ids, neg, ctrl, lat, 10)
     dt = time.time() - t0
-    f10 = 2135.06e9 * 10 + 2579.2e9
-    out["cpu_config1"] = dict(seconds=round(dt, 2), steps=10, images=1, cores=cores, images_per_s=round(1.0 / dt, 6),
-                              images_per_s_at_50_steps_scaled=round(1.0 / (dt * F_IMG_50 / f10), 6),
-                              cpu_tflops=round(f10 / dt / 1e12, 3),
-                              what="BASELINE configs[0]: torch-CPU fp32 oracle pipeline, 1 image 512x512, 1 prompt, 10 DDIM steps, timed directly")
+    del fam
+    sm = cpu_eval_sample(10.0)
+    return dict(value=round(1.0 / (dt * F_IMG_50 / F_IMG_10), 6), unit="images/s", cores=cores, kind="port", extrapolated=False,
+                seconds=round(dt, 2), config0_images_per_s=round(1.0 / dt, 6), steps_timed=10,
+                sample=f"BASELINE configs[0] timed directly: oracle pipeline (CLIP text + 10 x CFG evaluation of UNet + ControlNet + "
+                       f"VAE decode), 1 image 512x512, 1 prompt, 10 DDIM steps = {F_IMG_10 / 1e12:.2f} TFLOP in {dt:.1f} s on {cores} threads "
+                       f"(cgroup quota; os.cpu_count()={os.cpu_count()}); value = 1 / (seconds x 109.33 / {F_IMG_10 / 1e12:.2f}) "
+                       "images/s at the metric's 50 steps",
+                cpu_tflops=round(F_IMG_10 / dt / 1e12, 3), eval_sample=sm)
+
+
+def baselines_full(dev):
+    """SURVEY 8(d) comparator, `--baselines full` only (the directly timed CPU configs[0] run is the default `cpu_baseline`):
+      eager_port  : the same oracle modules on one MI355X through PyTorch-ROCm eager (rocBLAS / MIOpen / SDPA) under bf16
+                    autocast -- the "naive port" a maintainer gets by moving the reference's modules to the GPU -- one image
+                    per call (CFG batch 2), as the reference calls its pipeline."""
+    import torch
+
+    from oracle import sd_models as OM
+    from saspa_aug_amd import config as CFG
+    from saspa_aug_amd import weights as W
+    cores = effective_cpus()
+    torch.set_num_threads(cores)
+    cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
+    fam = W.synth_family(cfgs, seed=0)
+    out = {}
     # ---- eager port on the GPU ----
     sd_u = {k: v.to(dev) for k, v in fam["unet"].items()}
     sd_c = {k: v.to(dev) for k, v in fam["controlnet"].items()}
@@ -275,8 +306,9 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--baselines", choices=["sample", "full"], default="sample",
-                    help="full: also time BASELINE configs[0] on the CPU directly and the PyTorch-ROCm eager port (minutes)")
+    ap.add_argument("--baselines", choices=["config0", "quick", "full"], default="config0",
+                    help="config0 (default): cpu_baseline = BASELINE configs[0] timed directly on the host cores (~70 s); quick: only "
+                         "the 15 s evaluation sample, extrapolated; full: config0 + the PyTorch-ROCm eager port")
     ap.add_argument("--no-safety-checker", action="store_true",
                     help="A/B only: the reference never disables the SD-1.5 safety checker, so the default step runs it")
     ap.add_argument("--tiny", action="store_true", help="reduced-width family (plumbing check only; INVALID as a result)")
@@ -312,9 +344,14 @@ def run(args):
         raise RuntimeError(f"rank {rank}: no HIP device {local_rank} visible (bench.py measures the MI355X path; "
                            "--dry checks the multi-rank plumbing without a GPU)")
     dist = None
-    if world > 1:
+    # SASPA_FORCE_DIST=1: run the RCCL leg (process group on the device, device-tensor gather, all_reduce(MAX), barrier,
+    # destroy) at world size 1 too -- the rehearsal a one-GPU box allows before the driver's 8-GPU run
+    force_dist = os.environ.get("SASPA_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -361,6 +398,7 @@ def run(args):
         out = hot_path(batches[args.warmup + i])
         status.append(torch.ones(b, dtype=torch.int32, device=dev))       # per-item status (manifest)
     st = torch.cat(status)
+    gathered = None
     if dist is not None:
         gathered = [torch.empty_like(st) for _ in range(world)] if rank == 0 else None
         dist.gather(st, gathered, dst=0)
@@ -371,6 +409,8 @@ def run(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert out.shape == (b, res, res, 3) and out.dtype == torch.uint8
+    if gathered is not None:
+        assert all(int(g.sum()) == b * args.steps for g in gathered), "the status gather did not deliver every rank's vector"
 
     images = n_gpus * b * args.steps
     value = images / dt
@@ -399,6 +439,9 @@ def run(args):
                     flops_per_launch_avg=round(gm["flops"] / gm["launches"] / 1e9, 3),
                     note="achieved = sum of algorithmic FLOPs (2*M*N*K) of every launch of this kernel family in a 2-step "
                          "batch-8 generation / sum of their HIP-event durations")
+        roof["algorithmic_bytes"] = round(gm["bytes"] / gm["launches"])
+        roof["algorithmic_bytes_unit"] = ("operand bytes per launch (input pixels + weights + output + residual, each once, bf16), "
+                                          "avg over the same launches as `achieved`")
         total_ms = sum(d["ms"] for d in summ.values())
         roof["by_class"] = {
             k: dict(tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), frac=round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
@@ -412,8 +455,18 @@ def run(args):
             try:
                 tj = json.load(open(tfile))
                 roof["traffic"] = round(tj["hbm_bytes_per_launch"])
-                roof["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE, PMC, avg over the kernel family)"
+                roof["traffic_raw"] = round(tj["fetch_bytes_per_launch_raw"] + tj["write_bytes_per_launch"])
+                roof["traffic_unit"] = ("HBM bytes per launch, PMC, avg over the kernel family: `traffic` = FETCH_SIZE x2 + WRITE_SIZE "
+                                        "(upper bound: the gfx950 x2 correction applied to EVERY kernel), `traffic_raw` = FETCH_SIZE + "
+                                        "WRITE_SIZE uncorrected (lower bound); which correction fits which kernel: `traffic_by_kernel`")
                 roof["traffic_source"] = "profiles/" + os.path.basename(tfile)
+                if "by_kernel" in tj:
+                    roof["traffic_by_kernel"] = tj["by_kernel"]
+                if "hbm_bytes_per_launch_best" in tj:
+                    roof["traffic_best_estimate"] = round(tj["hbm_bytes_per_launch_best"])
+                roof["traffic_over_algorithmic"] = dict(
+                    raw=round(roof["traffic_raw"] / roof["algorithmic_bytes"], 3), x2=round(roof["traffic"] / roof["algorithmic_bytes"], 3),
+                    **({"best": round(roof["traffic_best_estimate"] / roof["algorithmic_bytes"], 3)} if "traffic_best_estimate" in roof else {}))
             except Exception:  # a malformed profile file must not take the bench line down
                 pass
         if "flash_attn" in summ:
@@ -427,7 +480,7 @@ def run(args):
     cpu = None
     extra = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.tiny:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(sample_only=(args.baselines == "quick"))
         if args.baselines == "full":
             extra = baselines_full(dev)
 
@@ -436,10 +489,14 @@ def run(args):
             "metric": "augmented images/sec (512x512, 50-step DDIM)", "value": round(value, 4), "unit": "images/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SD-v1.5 + Canny ControlNet, batch=8 512x512, 50 DDIM steps, CFG 7.5, ctrl-scale 0.75 "
-                                   "(BASELINE.json configs[1]); step = Canny + CLIP + 50x(UNet+ControlNet) + VAE decode",
+            "config": {"workload": f"SD-v1.5 + Canny ControlNet, batch={b} {res}x{res}, {s} DDIM steps, CFG 7.5, ctrl-scale 0.75 "
+                                   + ("(BASELINE.json configs[1])" if (b, res, s) == (8, 512, 50) else
+                                      "(NOT BASELINE.json configs[1], which is batch=8 512x512 50 steps)")
+                                   + f"; step = Canny + CLIP + {s}x(UNet+ControlNet) + VAE decode"
+                                   + ("" if not args.no_safety_checker else "; safety checker DISABLED (A/B only)"),
                        "batch_per_gpu": b, "resolution": res, "ddim_steps": s, "weights": "random-init, architecture-exact",
-                       "parallelism": f"dp{n_gpus} (image shards, one RCCL gather of the status vector)"},
+                       "parallelism": f"dp{n_gpus} (image shards, one RCCL gather of the status vector)",
+                       "process_group": (f"nccl (RCCL), world {world}" if dist is not None else "none (single process)")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if extra is not None:

@@ -79,9 +79,15 @@ if __name__ == "__main__":
     assert s.NUM_PER_IMAGE > 0
 
     dist = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:          # one process per GPU, RCCL over xGMI
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SASPA_FORCE_DIST", "0") == "1":
+        # one process per GPU, RCCL over xGMI (SASPA_FORCE_DIST=1: the same leg at world size 1 -- a one-GPU rehearsal)
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local_rank)
         s.DEVICE = f"cuda:{local_rank}"

@@ -23,7 +23,9 @@ GEMM_AUTO, GEMM_TILED, GEMM_WIDE, GEMM_WS, GEMM_AS = 0, 1, 2, 3, 4   # SaspaGemm
 
 # Optional launch recorder (bench.py / profiling only): called as recorder(kind, flops, call)
 # and must return call()'s result.  `flops` is the ALGORITHMIC work of the launch (2*M*N*K
-# for the implicit GEMM, 4*nq*nk*D per head for attention), used for the roofline figures.
+# for the implicit GEMM, 4*nq*nk*D per head for attention), used for the roofline figures; `meta` of a GEMM launch is
+# (M, N, K, kh, stride, upsample, concat, has_residual, output columns): kh = 0 linear, kh < 0 = -(batch count) of a raw
+# batched GEMM.
 _RECORDER = None
 
 
@@ -142,13 +144,17 @@ def _gn_stats_for(p, out, gn_unit, b, hw, n):
     """Epilogue GroupNorm statistics (SaspaGemmParams.gn_stats): allocate the [rows / 128, N / unit, 2] fp32 buffer, hang it
     on the output tensor (`saspa_gn` = (stats, unit): `groupnorm` picks it up and skips its statistics pass) -- when the
     shape allows it: bf16, whole 128-row blocks per image, whole 160-column tiles, dense output rows."""
+    if hasattr(out, "saspa_gn"):
+        del out.saspa_gn                  # a reused `out=`: statistics of an earlier launch must not outlive this one
     if not gn_unit or not gn_fusion_enabled() or out.dtype != torch.bfloat16:
         return None
     if hw % 128 or n % 160 or 80 % gn_unit or gn_unit % 2 or gn_unit > 16 or out.shape[-1] != n or p.ldo % 8 or (p.residual and p.ldr % 8):
         return None
     stats = torch.empty((b * hw // 128, n // gn_unit, 2), device=out.device, dtype=torch.float32)
     p.gn_stats, p.gn_unit = _ptr(stats), int(gn_unit)
-    out.saspa_gn = (stats, int(gn_unit))
+    # (statistics, unit, the buffer and tensor version they describe): `groupnorm` re-checks the last two, so a tensor that
+    # was re-pointed or written in place through torch since the launch falls back to its own statistics pass
+    out.saspa_gn = (stats, int(gn_unit), out.data_ptr(), out._version)
     return stats
 
 
@@ -218,7 +224,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     _gs = _gn_stats_for(p, out, gn_unit, b, ho * wo, n)  # noqa: F841   (set BEFORE the split-K heuristic looks at p)
     _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
     _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
-            (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0))
+            (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0, residual is not None, n // 2 if act == ACT_GEGLU else n))
     return out
 
 
@@ -294,7 +300,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     if act == ACT_GEGLU:
         p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),
-            (m, n, k, 0, 1, 0, False))
+            (m, n, k, 0, 1, 0, False, residual is not None, n // 2 if act == ACT_GEGLU else n))
     if x.dim() != 2 and out.dim() == 2:
         return out.reshape(*x.shape[:-1], out.shape[-1])
     return out
@@ -324,7 +330,7 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.so1, p.so2 = so
     p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k * nb1 * nb2,
-            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"), (m, n, k, -nb1 * nb2, 1, 0, False))
+            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"), (m, n, k, -nb1 * nb2, 1, 0, False, residual is not None, n))
     return out
 
 
@@ -384,7 +390,12 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
     if out is None:
         out = torch.empty((b, h, w, ctot), device=x.device, dtype=x.dtype)
     # statistics left by the producers' epilogues (conv(..., gn_unit=...)): no statistics pass
-    g0, g1 = getattr(x, "saspa_gn", None), (getattr(x2, "saspa_gn", None) if x2 is not None else None)
+    def _fresh(t):
+        g = getattr(t, "saspa_gn", None) if t is not None else None
+        if g is None or g[2] != t.data_ptr() or g[3] != t._version or g[0].shape[0] * 128 != t.shape[0] * t.shape[1] * t.shape[2]:
+            return None
+        return g
+    g0, g1 = _fresh(x), _fresh(x2)
     fused = (g0 is not None and (x2 is None or g1 is not None) and gn_fusion_enabled() and (h * w) % 128 == 0
              and (x2 is None or g1[1] == g0[1]) and c0 % g0[1] == 0 and c1 % g0[1] == 0 and (ctot // groups) % g0[1] == 0
              and g0[0].shape[1] * g0[1] == c0 and (x2 is None or g1[0].shape[1] * g1[1] == c1))

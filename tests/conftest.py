@@ -1,15 +1,11 @@
 import os
 import sys
-import time
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-
-_SESSION_T0 = time.time()
 
 
 def _effective_cpus():
@@ -41,12 +37,6 @@ _FIRST = ("test_production_gpu.py", "test_production_families_gpu.py")
 
 def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda it: 0 if it.fspath.basename in _FIRST else 1)      # stable: the order inside each class is kept
-
-
-@pytest.fixture
-def heavy_budget():
-    """Kept as a no-op so that older test signatures still resolve: nothing is skipped on a time budget any more."""
-    return None
 
 
 @pytest.fixture(scope="session", autouse=True)

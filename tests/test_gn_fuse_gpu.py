@@ -24,7 +24,7 @@ def _stats_ref(out, unit):
 
 
 def _check(out, unit=10):
-    stats, u = out.saspa_gn
+    stats, u = out.saspa_gn[:2]
     assert u == unit and stats.shape == (out.numel() // out.shape[-1] // 128, out.shape[-1] // unit, 2)
     ref = _stats_ref(out, unit)
     got = stats.double().cpu()

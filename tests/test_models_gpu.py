@@ -226,13 +226,15 @@ def test_pipeline_fp32_parity_sd15_config1(dev):
     assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)
 
 
-def test_pipeline_fp32_parity_sd15_512(dev):
-    """The BASELINE resolution itself: full SD-v1.5 + Canny ControlNet + VAE + CLIP-L widths, 1 image 512x512 (64x64
-    latents, 4 096 tokens at level 0), 2 DDIM steps, fp32 path vs the CPU oracle, atol 1e-3 per pixel."""
+def test_pipeline_fp32_parity_sd15_config0_512_10steps(dev):
+    """BASELINE configs[0] at its stated size AND length together: full SD-v1.5 + Canny ControlNet + VAE + CLIP-L widths,
+    1 image 512x512 (64x64 latents, 4 096 tokens at level 0), 1 prompt, 10 DDIM steps, fp32 path vs the CPU oracle, the
+    north-star bar (per-pixel atol 1e-3 in [0,1], <= 1 u8 level).  ~70 s of CPU oracle on the box's 16 cores.  Reference
+    call sites: run_aug/run_aug.py:235-241, 268-269, 278."""
     cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
     fam = W.synth_family(cfgs, seed=0)
-    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, 512, 512, 2)
-    print(f"fp32 SD-1.5 512x512, 2 steps: max|d|={d01:.2e} u8 diff {du8} PSNR={psnr:.1f}")
+    d01, du8, psnr = _pipeline_case(cfgs, fam, dev, torch.float32, 512, 512, 10)
+    print(f"fp32 SD-1.5 configs[0] 512x512, 10 steps: max|d|={d01:.2e} u8 diff {du8} PSNR={psnr:.1f}")
     assert d01 < 1e-3 and du8 <= 1, (d01, du8, psnr)
 
 

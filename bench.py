@@ -340,6 +340,12 @@ def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE JSON line: RCCL prints a version banner to stdout when the first communicator is created
+    # (seen on the MI355X box: "RCCL version : ... / Librccl path : ..."), so file descriptor 1 points at stderr for the whole
+    # run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         raise RuntimeError(f"rank {rank}: no HIP device {local_rank} visible (bench.py measures the MI355X path; "
                            "--dry checks the multi-rank plumbing without a GPU)")
@@ -503,9 +509,13 @@ def run(args):
             line["baselines_full"] = extra
         if args.tiny:
             line["config"]["workload"] = "TINY plumbing run -- not a valid result"
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     return 0
 
 

@@ -118,11 +118,34 @@ def round8(n):
     return (n + 7) // 8 * 8
 
 
+_TWIN = [False]
+
+
+class twin_branch:
+    """Context: the launches issued inside run on ONE of two concurrent graph branches that walk the same layer shapes at the
+    same time (UNet encoder || ControlNet encoder, pipeline._StepGraph).  The split-K heuristic sizes a launch for the whole
+    chip; with a twin beside it, half the K slices fill the chip just as well -- half the fp32 slab traffic, and for the
+    convs of the 32x32 / 16x16 levels (128 wide tiles, ksplit 2) no slabs and no reduce launch at all.  SASPA_TWIN_KS=0 turns
+    the adjustment off (A/B knob).  Results differ from the single-branch dispatch only by the summation order of K."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _TWIN[0]
+        _TWIN[0] = self.on and os.environ.get("SASPA_TWIN_KS", "1") != "0"
+
+    def __exit__(self, *a):
+        _TWIN[0] = self.prev
+
+
 def _set_splitk(p, m, n, k, t, force=None):
     """Split-K factor from the library's own heuristic (saspa_gemm_suggest_ksplit: every other field of p is already
     filled in) or the caller's override; allocates the fp32 slab workspace."""
     p.ksplit, p.workspace = 1, None
     ks = _lib.load().saspa_gemm_suggest_ksplit(C.byref(p)) if force is None else int(force)
+    if force is None and _TWIN[0] and ks > 1:
+        ks = (ks + 1) // 2
     if ks > 1:
         ws = torch.empty((ks * m * n,), device=t.device, dtype=torch.float32)
         p.ksplit, p.workspace = ks, C.c_void_p(ws.data_ptr())

@@ -135,9 +135,10 @@ class _StepGraph:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=x.device)
             self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                cmid, cfeats = pipe.controlnet.encode(x, None, conv_in_residual=self.cemb)
-            mid, skips = pipe.unet.encode(x, None)
+            with ops.twin_branch(ops._RECORDER is None):   # both encoders walk the same shapes side by side: half the K slices each
+                with torch.cuda.stream(self.side):
+                    cmid, cfeats = pipe.controlnet.encode(x, None, conv_in_residual=self.cemb)
+                mid, skips = pipe.unet.encode(x, None)
             main.wait_stream(self.side)
             skips2, mid2 = pipe.controlnet.zero_convs(cmid, cfeats, self.cscale, skips, mid)
         else:
@@ -337,9 +338,16 @@ class StableDiffusionControlNetPipeline:
         eps = torch.zeros_like(x2)
 
         def evaluate(i):
-            mid, skips = self.unet.encode(x2, i)
-            if self.controlnet is not None:
-                skips, mid = self.controlnet.forward(x2, i, cemb2, cscale, skips, mid)
+            if self.controlnet is None:
+                mid, skips = self.unet.encode(x2, i)
+            else:
+                # the same launches, with the same dispatch decisions, as the two-branch graph step (_StepGraph._step): the
+                # split-K of the paired encoders is sized for two concurrent branches (ops.twin_branch) -- except under a
+                # launch recorder, which times every launch ALONE and therefore gets the full-chip dispatch
+                with ops.twin_branch(fork_enabled() and ops._RECORDER is None):
+                    cmid, cfeats = self.controlnet.encode(x2, i, conv_in_residual=cemb2)
+                    mid, skips = self.unet.encode(x2, i)
+                skips, mid = self.controlnet.zero_convs(cmid, cfeats, cscale, skips, mid)
             self.unet.decode(mid, skips, i, out=eps)
 
         if isinstance(sch, PNDMScheduler):

@@ -45,7 +45,10 @@ def test_graph_replay_equals_eager_sd15(dev, dtype, monkeypatch):
     try:
         assert not graphs_enabled()
         got = pipe.generate_batch(*_inputs(cfgs, 2, 64, 64, 11), 4, return_latents=True)[1]
-        assert torch.equal(got, eager[0])
+        # under a recorder every launch is timed alone and takes the full-chip split-K (no ops.twin_branch halving): the
+        # same sums in another K order -- equal up to rounding, not bit for bit
+        tol = 2e-5 if dtype == torch.float32 else 6e-2
+        assert (got.float() - eager[0].float()).abs().max().item() <= tol * eager[0].float().abs().max().item()
     finally:
         ops.set_recorder(None)
 

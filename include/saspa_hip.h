@@ -145,6 +145,13 @@ typedef struct SaspaGemmParams {
   long long st;
   int n_split;
   int rows_per_batch;
+  /* Concurrency hint (ABI 15).  0: the launch has the chip to itself (the default).  1: a TWIN launch of the same shape
+   * runs beside it on another stream -- the two encoder branches of a sampling step (UNet encoder || ControlNet encoder walk
+   * identical layer shapes side by side) -- so AUTO sizes tile choice and split-K for HALF the CUs: the convs / projections
+   * of the 32x32 level (128 tiles of 256 x 320) run un-split on the 8-wave kernel next to their twin instead of on two K
+   * slices with fp32 slabs and a reduce launch, the 16x16 level takes two slices instead of four.  Only saspa_gemm_suggest_ksplit
+   * and the AUTO dispatch read it; the result differs from sharing = 0 by the summation order of K only. */
+  int sharing;
 } SaspaGemmParams;
 /* Non-zero if the A-stationary kernel can run the problem (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at least 192
  * blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or fused GEGLU,

@@ -1041,13 +1041,14 @@ static bool ws_round_ok(long long t) {
   return t * 100 >= rounds * 256 * 85;
 }
 
-static int pp_choose_ksplit(long long t, int ktiles, long long mn, int fn) {
+// ncu: CUs the launch may count on -- 256, or 128 when a twin launch shares the chip (SaspaGemmParams.sharing)
+static int pp_choose_ksplit(long long t, int ktiles, long long mn, int fn, int ncu = 256) {
   const double c0 = 20.0, c1 = fn == 5 ? 1.34 : 1.07;
   int best = 1;
   double best_cost = 1e30;
   for (int ks = 1; ks <= 8; ++ks) {
     if (ks > 1 && ktiles / ks < 8) break;
-    const long long rounds = (t * ks + 255) / 256;
+    const long long rounds = (t * ks + ncu - 1) / ncu;
     double cost = (double)rounds * (c0 + (double)((ktiles + ks - 1) / ks) * c1);
     if (ks > 1) cost += 5.0 + (4.0 * ks + 4.0) * (double)mn / 4.0e6;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
@@ -1086,6 +1087,8 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       if (can && pp_mode_g != 0 && p.variant == SASPA_GEMM_AUTO && p.K >= 960) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / 320);
         static const bool model_g = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);
+        // a twin launch beside this one (sharing): a whole round of the HALF chip is 128 tiles, whatever K (tools/twin_sweep.py)
+        if (model_g && p.sharing && ksplit == 1 && t >= 96) return saspa_gemm_pp_launch(p, s, 1, 5);
         if (model_g && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, 5);
         if (t >= (model_g ? 144 : 192) && (!model_g || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, 5);
         static const bool wide_ks_g = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);
@@ -1143,6 +1146,10 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       if (fn) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
         static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);   // A/B knob
+        // a twin launch of the same shape shares the chip (SaspaGemmParams.sharing): 96+ wide tiles are a whole round of this
+        // launch's half, for every K the wide kernel takes -- pair times of tools/twin_sweep.py (profiles/r4_twin_sweep.txt):
+        // (16384, 640, 2560) + residual 112 vs 152 us, conv (16384, 640, 2880) 106 vs 139, conv (16384, 640, 5760) 183 vs 270
+        if (model && p.sharing && ksplit == 1 && t >= 96) return saspa_gemm_pp_launch(p, s, 1, fn);
         // long K, one slice chosen by the cost model (suggest_ksplit) and at least half the CUs busy: still the wide kernel
         if (model && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, fn);
         // 3/4 of a wave of tiles or more: no split-K.  (144 <= t < 192 is the 512x704 / 512x768 buckets' 32x44 / 32x48 level:
@@ -1198,8 +1205,10 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
     static const int ws_max = getenv("SASPA_GEMM_WS_MAXTILES") ? atoi(getenv("SASPA_GEMM_WS_MAXTILES")) : 512;
     const int bn_t = (p.N % 160 == 0) ? 160 : 128;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + bn_t - 1) / bn_t);
-    if (ws_on && !p.gn_stats && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 && t128 >= 256 && t128 < ws_max &&
-        ws_round_ok(t128) && saspa_gemm_ws_eligible(p))
+    // (not with a twin launch beside a long-K layer: there two K slices on the 8-wave kernel win, pair times 124 vs 146 us at
+    // (4096, 1280, 5120) + residual, tools/twin_sweep.py)
+    if (ws_on && !(p.sharing && p.K >= 4096) && !p.gn_stats && p.dtype == SASPA_BF16 && p.variant == SASPA_GEMM_AUTO && p.kh == 1 && p.kw == 1 &&
+        t128 >= 256 && t128 < ws_max && ws_round_ok(t128) && saspa_gemm_ws_eligible(p))
       return 1;
   }
   if (wide_ks && p.dtype == SASPA_BF16 && p.K >= 4096 && saspa_gemm_pp_eligible(p)) {
@@ -1217,9 +1226,10 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
         }
       } else if (t >= 24) {
         // rounds x slice length + reduce: pp_choose_ksplit; a single slice is taken on the wide kernel too when it leaves at
-        // least half the CUs busy (dispatch() applies the same rule)
-        const int ks = pp_choose_ksplit(t, ktiles, (long long)p.M * p.N, fn);
-        if (ks > 1 || t >= 128) return ks;
+        // least half the CUs busy (dispatch() applies the same rule).  With a twin launch beside it (sharing) the launch
+        // counts on half the chip: 128 tiles need no slices, 64 tiles two instead of four
+        const int ks = pp_choose_ksplit(t, ktiles, (long long)p.M * p.N, fn, p.sharing ? 128 : 256);
+        if (ks > 1 || t >= (p.sharing ? 64 : 128)) return ks;
       }
     }
   }

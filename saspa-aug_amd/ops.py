@@ -123,10 +123,11 @@ _TWIN = [False]
 
 class twin_branch:
     """Context: the launches issued inside run on ONE of two concurrent graph branches that walk the same layer shapes at the
-    same time (UNet encoder || ControlNet encoder, pipeline._StepGraph).  The split-K heuristic sizes a launch for the whole
-    chip; with a twin beside it, half the K slices fill the chip just as well -- half the fp32 slab traffic, and for the
-    convs of the 32x32 / 16x16 levels (128 wide tiles, ksplit 2) no slabs and no reduce launch at all.  SASPA_TWIN_KS=0 turns
-    the adjustment off (A/B knob).  Results differ from the single-branch dispatch only by the summation order of K."""
+    same time (UNet encoder || ControlNet encoder, pipeline._StepGraph).  The library sizes a launch for the whole chip; with
+    a twin beside it half the chip is what it gets, so the launches carry SaspaGemmParams.sharing = 1 (ABI 15): tile choice
+    and split-K are made for 128 CUs -- the convs / projections of the 32x32 level (128 wide tiles) run un-split next to
+    their twin (no fp32 slabs, no reduce launch), the 16x16 level takes two K slices instead of four.  SASPA_TWIN_KS=0 turns
+    the hint off (A/B knob).  Results differ from the single-branch dispatch only by the summation order of K."""
 
     def __init__(self, on=True):
         self.on = bool(on)
@@ -143,9 +144,8 @@ def _set_splitk(p, m, n, k, t, force=None):
     """Split-K factor from the library's own heuristic (saspa_gemm_suggest_ksplit: every other field of p is already
     filled in) or the caller's override; allocates the fp32 slab workspace."""
     p.ksplit, p.workspace = 1, None
+    p.sharing = 1 if _TWIN[0] else 0
     ks = _lib.load().saspa_gemm_suggest_ksplit(C.byref(p)) if force is None else int(force)
-    if force is None and _TWIN[0] and ks > 1:
-        ks = (ks + 1) // 2
     if ks > 1:
         ws = torch.empty((ks * m * n,), device=t.device, dtype=torch.float32)
         p.ksplit, p.workspace = ks, C.c_void_p(ws.data_ptr())

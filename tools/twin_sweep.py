@@ -21,7 +21,7 @@ s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
 def time_pair(f1, f2, n=20):
     """f1 on stream s1 and f2 on stream s2, n iterations each, issued interleaved; wall time of both per iteration."""
-    for _ in range(3):
+    for _ in range(40):          # warm: clocks drop while the host builds the next shape's operands, lazy code-object loads
         with torch.cuda.stream(s1): f1()
         with torch.cuda.stream(s2): f2()
     torch.cuda.synchronize()
@@ -37,7 +37,7 @@ def time_pair(f1, f2, n=20):
 
 
 def time_single(f, n=20):
-    for _ in range(3): f()
+    for _ in range(40): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -51,7 +51,7 @@ def run(label, flops, make):
     row = []
     cases = [("single x2", 0, None, False, True), ("auto", 0, None, False, False), ("auto+twin", 0, None, True, False),
              ("tiled k1", 1, 1, False, False), ("tiled k2", 1, 2, False, False), ("wide k1", 2, 1, False, False),
-             ("wide k2", 2, 2, False, False), ("ws", 3, 1, False, False)]
+             ("wide k2", 2, 2, False, False), ("ws", 3, 1, False, False), ("auto (again)", 0, None, False, False)]
     for (name, variant, ks, twin, single) in cases:
         try:
             f1, f2 = make(variant, ks, twin)

@@ -408,6 +408,43 @@ typedef struct SaspaHedFuseParams {
 } SaspaHedFuseParams;
 int saspa_hed_fuse(const SaspaHedFuseParams* p, void* stream);
 
+/* ---- cross-attention half of a level-0 transformer block in one launch (ABI 16) --------------------------------------
+ * out = residual + to_out( softmax( to_q(LayerNorm(x)) K^T ) V ) + bias for C = 320 channels, 8 heads of 40 and nk <= 96 keys:
+ * BasicTransformerBlock.norm2 -> attn2.to_q -> scaled_dot_product_attention over the text tokens -> attn2.to_out.0 -> residual
+ * (diffusers attention.py / attention_processor.py; the reference reaches it through pipe(), run_aug/run_aug.py:278).
+ * Replaces three launches (LayerNorm + to_q, flash attention, to_out + residual) that each stream the [M, 320] token matrix.
+ * Operands in the layouts the kernel's MFMA chain consumes (saspa_aug_amd/weights.py: pack_xattn_*; built once):
+ *   w    [640][ldw >= 320] bf16: rows 0..319 = to_q rows (softmax scale * log2 e folded in) ordered [heads 0-7: channels 0-31 |
+ *        heads 0-7: channels 32-39]; rows 320..639 = to_out with its K columns in the order the attention stage emits them.
+ *   bias [640] fp32: 320 zeros, then the to_out bias.
+ *   kf / vf: per sample (byte strides kf_stride >= 73 728, vf_stride >= 98 304) the text K and V^T of this block cut into
+ *        MFMA A-operand fragments [head][key block 3][K-step 3][lane 64][8 bf16] and [head][channel block 2][K-step 6][lane 64][8 bf16]
+ *        (zero-padded; V^T row 40 of every head = 1.0: the softmax denominator rides the same MFMAs).  Time-invariant.
+ * M % 256 == 0, rows_per_sample % 256 == 0 (a workgroup's 256 rows share one sample's keys), all pitches % 8 == 0,
+ * 16-byte aligned operands, 32-bit byte offsets (M * pitch * 2 < 2 GiB); SASPA_ERANGE / SASPA_EALIGN otherwise. */
+typedef struct SaspaXattnBlockParams {
+  const void* x;             /* [M][ldx] bf16: the block's hidden states (LayerNorm input) */
+  int ldx;
+  const void* residual;      /* [M][ldr] bf16: added to the result (the reference adds x itself) */
+  int ldr;
+  long long M;
+  int rows_per_sample;       /* tokens per sample (H/8 * W/8) */
+  const float* ln_gamma;     /* [320] */
+  const float* ln_beta;
+  float ln_eps;
+  const void* w;             /* [640][ldw] bf16, see above */
+  int ldw;
+  const float* bias;         /* [640] */
+  const void* kf;
+  long long kf_stride;       /* bytes per sample */
+  const void* vf;
+  long long vf_stride;
+  int nk;                    /* valid keys (77) */
+  void* out;                 /* [M][ldo] bf16 */
+  int ldo;
+} SaspaXattnBlockParams;
+int saspa_xattn_block(const SaspaXattnBlockParams* p, void* stream);
+
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);
 

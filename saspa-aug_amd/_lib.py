@@ -28,6 +28,15 @@ class GemmParams(C.Structure):
     ]
 
 
+class XattnBlockParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int), ("M", C.c_longlong),
+        ("rows_per_sample", C.c_int), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("w", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p), ("kf", C.c_void_p), ("kf_stride", C.c_longlong),
+        ("vf", C.c_void_p), ("vf_stride", C.c_longlong), ("nk", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int),
+    ]
+
+
 class AttnParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("ldq", C.c_int), ("sqb", C.c_longlong),
@@ -105,6 +114,7 @@ SYMBOLS = {
     "saspa_vae_sample_noise": (_I, [_I, _P, _P, _P, _P, _LL, _F, _F, _F, _P]),
     "saspa_cfg_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P]),
     "saspa_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
+    "saspa_xattn_block": (_I, [C.POINTER(XattnBlockParams), _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

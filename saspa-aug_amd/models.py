@@ -18,6 +18,7 @@ Layout decisions (MI355X-first, not a translation of diffusers' NCHW modules):
 
 Semantics follow [upstream] diffusers 0.32.2 as listed in SURVEY.md 3.2 / 8(a7)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -100,6 +101,11 @@ class _Packed:
 # ------------------------------------------------------------------------------------------
 # attention (shared by UNet / ControlNet / VAE / CLIP)
 # ------------------------------------------------------------------------------------------
+def xattn_enabled():
+    """SASPA_XATTN=0: the cross-attention half of the level-0 blocks runs as three launches again (A/B knob)."""
+    return os.environ.get("SASPA_XATTN", "1") != "0"
+
+
 def project_vt(x, wv, nk):
     """vt[b] = Wv @ x_b^T -> [B, C, ld] with keys contiguous (pad columns zero)."""
     b, n, k = x.shape
@@ -155,6 +161,7 @@ class _Net:
         # saspa_gemm_fp8 (bf16 networks only; blocks whose width is not a multiple of 128 stay bf16)
         self.fp8 = bool(fp8) and dtype == torch.bfloat16
         self.fp8_blocks = set()
+        self.xattn_blocks = set()         # transformer blocks whose cross-attention half can run as one launch (ops.xattn_block)
         self.pk = _Packed(sd, dev, dtype)
         self.p = self.pk.p
         self.temb_tables = {}
@@ -197,6 +204,13 @@ class _Net:
             pk.attn(t + ".attn2", False, qscale=qs)
             if qs is not None:
                 self.qscaled[t] = qs
+            if qs is not None and c == W.XATTN_C and heads == W.XATTN_HEADS and not self.fp8 and (t + ".attn2.to_q.bias") not in pk.sd:
+                # level-0 blocks: norm2 -> attn2.to_q -> attention over the text keys -> attn2.to_out + residual as ONE launch
+                # (saspa_xattn_block); the stacked [to_q' ; to_out'] matrix in the order its MFMA chain consumes (weights.pack_xattn_w)
+                xw, xb = W.pack_xattn_w(pk.sd[t + ".attn2.to_q.weight"].float() * float(qs), pk.sd[t + ".attn2.to_out.0.weight"].float(),
+                                        pk.sd[t + ".attn2.to_out.0.bias"].float())
+                self.p[t + ".attn2.xw"], self.p[t + ".attn2.xb"] = xw.to(self.dev, self.dtype), _f32(xb, self.dev)
+                self.xattn_blocks.add(t)
             if self.dtype == torch.bfloat16 and c // heads <= 160 and (t + ".attn1.qk.b") not in self.p:
                 # [to_q; to_k; to_v] in one matrix: at level 0 for the A-stationary kernel (LayerNorm fused, V^T written
                 # transposed by the same launch: ops.linear(ln=, out_t=)), elsewhere for ONE projection launch whose V
@@ -314,7 +328,12 @@ class _Net:
             a = t + ".attn2"
             k = ops.linear(ctx, self.p[a + ".k.w"])                     # [B,77,C]
             vt = project_vt(ctx, self.p[a + ".v.w"], n)                 # [B,C,80]
-            self.ctx_kv[t] = (k, vt, n)
+            if t in self.xattn_blocks and xattn_enabled():
+                # the same K / V cut into the MFMA operand fragments of saspa_xattn_block (time-invariant, like K / V^T themselves)
+                kf, vf = W.xattn_kv_fragments(k, vt[:, :, :n].transpose(1, 2).contiguous())
+                self.ctx_kv[t] = (k, vt, n, kf, vf)
+            else:
+                self.ctx_kv[t] = (k, vt, n)
 
     # ---- blocks ----
     def resnet(self, pfx, x, step, eps, x2=None):
@@ -378,7 +397,7 @@ class _Net:
                 # W8A8: LayerNorm + per-token quantisation in one pass, e4m3 x e4m3 MFMA, scales applied in the epilogue
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
                 q = ops.linear_fp8(q8, s8, p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"])
-                k, vtc, nk = self.ctx_kv[t]
+                k, vtc, nk = self.ctx_kv[t][:3]
                 o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
@@ -387,14 +406,20 @@ class _Net:
                 h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
                 continue
             # cross-attention against the cached text K / V^T
-            if fuse and ops.linear_ln_fusable(h, p[t + ".attn2.q.w"]):
-                q = ops.linear(h, p[t + ".attn2.q.w"], ln=(p[t + ".norm2.g"], p[t + ".norm2.b"], 1e-5))
+            kv = self.ctx_kv[t]
+            if fuse and len(kv) == 5 and n % 256 == 0 and kv[2] <= 96:
+                # level 0 of a full-size batch: LayerNorm + to_q + attention + to_out + residual in one launch
+                h = ops.xattn_block(h, (p[t + ".norm2.g"], p[t + ".norm2.b"], 1e-5), p[t + ".attn2.xw"], p[t + ".attn2.xb"], kv[3], kv[4],
+                                    kv[2], n)
             else:
-                n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
-                q = ops.linear(n2, p[t + ".attn2.q.w"])
-            k, vtc, nk = self.ctx_kv[t]
-            o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
-            h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
+                if fuse and ops.linear_ln_fusable(h, p[t + ".attn2.q.w"]):
+                    q = ops.linear(h, p[t + ".attn2.q.w"], ln=(p[t + ".norm2.g"], p[t + ".norm2.b"], 1e-5))
+                else:
+                    n2 = ops.layernorm(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
+                    q = ops.linear(n2, p[t + ".attn2.q.w"])
+                k, vtc, nk = kv[:3]
+                o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
+                h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
             # (with a ragged last round of row blocks -- 512x704 -- the wave-specialised kernel + LayerNorm is as fast: == 2)
             if fuse and t in self.fused_geglu and ops.linear_ln_fusable(h, p[t + ".ff.net.0.proj.w"], act=ops.ACT_GEGLU) == 2:

@@ -329,6 +329,43 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     return out
 
 
+def xattn_block(x, ln, w, bias, kf, vf, nk, rows_per_sample, residual=None, out=None):
+    """The cross-attention half of a level-0 transformer block in one launch (saspa_xattn_block, include/saspa_hip.h):
+    out = residual + to_out(softmax(to_q(LayerNorm(x)) K^T) V) + bias.  x [..., 320] bf16 (uniform row pitch), ln = (gamma, beta,
+    eps), w / bias from weights.pack_xattn_w, kf / vf [B, ...] from weights.xattn_kv_fragments, residual defaults to x."""
+    _check_dev(x, w, bias, kf, vf, residual, out)
+    lib = _lib.load()
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c) if x.dim() != 2 else x
+    m = x2.shape[0]
+    if x.dtype != torch.bfloat16 or c != 320:
+        raise ValueError("xattn_block: bf16 rows of 320 channels")
+    r2 = x2 if residual is None else (residual.reshape(-1, c) if residual.dim() != 2 else residual)
+    if out is None:
+        out = torch.empty((m, c), device=x.device, dtype=x.dtype)
+    o2 = out.view(-1, c) if out.dim() != 2 else out
+    g, b_, eps = ln
+    p = _lib.XattnBlockParams()
+    p.x, p.ldx = _ptr(x2), x2.stride(0)
+    p.residual, p.ldr = _ptr(r2), r2.stride(0)
+    p.M, p.rows_per_sample = m, int(rows_per_sample)
+    p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(g), _ptr(b_), float(eps)
+    p.w, p.ldw, p.bias = _ptr(w), w.stride(0), _ptr(bias)
+    p.kf, p.kf_stride = _ptr(kf), kf.stride(0) * kf.element_size()
+    p.vf, p.vf_stride = _ptr(vf), vf.stride(0) * vf.element_size()
+    p.nk = int(nk)
+    p.out, p.ldo = _ptr(o2), o2.stride(0)
+    if kf.shape[0] * rows_per_sample != m or vf.shape[0] != kf.shape[0]:
+        raise ValueError(f"xattn_block: {kf.shape[0]} samples of {rows_per_sample} rows do not make {m} rows")
+    # algorithmic work: to_q + to_out (2 x 2 M C^2) and the two attention products over the nk keys (2 x 2 M nk C)
+    flops = 4.0 * m * c * c + 4.0 * m * nk * c
+    _launch("gemm", flops, lambda: _lib.check(lib.saspa_xattn_block(C.byref(p), _stream()), "saspa_xattn_block"),
+            (m, 2 * c + 2 * nk, c, 0, 1, 0, False, True, c))
+    if x.dim() != 2 and out.dim() == 2:
+        return out.reshape(*x.shape[:-1], c)
+    return out
+
+
 def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=1.0, residual=None, ldr=0, act=ACT_NONE):
     """Raw batched GEMM out[z] = act(alpha * a[z] @ w[z]^T) (+ residual[z], same batch strides as out); s* = (stride1,
     stride2) in elements.  ``a``/``w``/``out``/``residual`` are tensors whose data_ptr is the z=0 origin."""

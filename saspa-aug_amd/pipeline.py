@@ -97,13 +97,15 @@ class _StepGraph:
             if first:
                 self.tables.append(net.temb_all.clone())
                 self.curs.append(torch.zeros_like(net.temb_all[0]))
-                self.ctx_kv.append({t: (k.clone(), vt.clone(), n) for t, (k, vt, n) in net.ctx_kv.items()})
+                # (K, V^T, key count[, K / V^T fragments of the fused cross-attention launch]): tensors are cloned into static buffers
+                self.ctx_kv.append({t: tuple(e.clone() if torch.is_tensor(e) else e for e in kv) for t, kv in net.ctx_kv.items()})
             else:
                 if refresh_t:
                     self.tables[i].copy_(net.temb_all)
-                for t, (k, vt, n) in net.ctx_kv.items():
-                    self.ctx_kv[i][t][0].copy_(k)
-                    self.ctx_kv[i][t][1].copy_(vt)
+                for t, kv in net.ctx_kv.items():
+                    for dst, src in zip(self.ctx_kv[i][t], kv):
+                        if torch.is_tensor(src):
+                            dst.copy_(src)
         self.x.copy_(x)
         self.cemb.copy_(cemb)
         if self.unipc:

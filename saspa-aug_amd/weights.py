@@ -708,3 +708,88 @@ def pack_geglu(w, b):
         idx += list(range(t * half, (t + 1) * half)) + list(range(f + t * half, f + (t + 1) * half))
     idx = torch.tensor(idx)
     return w[idx].contiguous(), b[idx].contiguous()
+
+
+# ---- fused cross-attention block (csrc/saspa_xattn.hip, include/saspa_hip.h: SaspaXattnBlockParams) -------------------------
+XATTN_C, XATTN_HEADS, XATTN_D = 320, 8, 40
+
+
+def _xattn_rho(pos):
+    """Row (0..15) of a 16-deep MFMA K-step that operand position `pos` = 8 * (lane half) + element j holds when the operand is
+    an accumulator tile packed to bf16 (v_mfma_f32_32x32x16_bf16: register r of lane half h is row (r & 3) + 8 (r >> 2) + 4 h)."""
+    h, j = pos >> 3, pos & 7
+    return 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def pack_xattn_w(wq, wo, bo):
+    """to_q [320, 320] (softmax scale * log2 e already folded in), to_out [320, 320], to_out bias [320] (fp32, host) -> the stacked
+    [640, 320] matrix and the [640] bias saspa_xattn_block streams:
+      rows 0..319   to_q rows ordered [head 0..7: channels 0..31 | head 0..7: channels 32..39] -- a head is one whole 32-row
+                    accumulator block plus a quarter of a tail block;
+      rows 320..639 to_out with its K columns in the order the attention stage emits O^T: K-step ks < 16 = channels 16 (ks & 1)
+                    + rho of head ks >> 1, K-steps 16..19 = the channel-32..39 tails of heads (2 i, 2 i + 1), inside every K-step
+                    the operand positions follow `_xattn_rho`."""
+    d, c = XATTN_D, XATTN_C
+    assert tuple(wq.shape) == (c, c) and tuple(wo.shape) == (c, c) and bo.numel() == c
+    rows = [b * d + i for b in range(XATTN_HEADS) for i in range(32)] + [(t // 8) * d + 32 + (t % 8) for t in range(64)]
+    feat = []
+    for ks in range(c // 16):
+        for pos in range(16):
+            rho = _xattn_rho(pos)
+            if ks < 16:
+                feat.append((ks >> 1) * d + 16 * (ks & 1) + rho)
+            else:
+                feat.append((2 * (ks - 16) + (rho >> 3)) * d + 32 + (rho & 7))
+    assert sorted(rows) == list(range(c)) and sorted(feat) == list(range(c))
+    w = torch.cat([wq.float()[torch.tensor(rows)], wo.float()[:, torch.tensor(feat)]], 0).contiguous()
+    bias = torch.cat([torch.zeros(c), bo.float().reshape(-1)]).contiguous()
+    return w, bias
+
+
+_XATTN_IDX = {}
+
+
+def _xattn_frag_indices(device):
+    """Gather indices into a per-head [96 keys][48 channel slots] plane for the K fragments [3][3][64][8] and the V^T fragments
+    [2][6][64][8] of saspa_xattn_block (slot 47 is always zero: the 'nothing here' target)."""
+    key = str(device)
+    if key in _XATTN_IDX:
+        return _XATTN_IDX[key]
+    kf = torch.zeros((3, 3, 64, 8), dtype=torch.long)
+    vf = torch.zeros((2, 6, 64, 8), dtype=torch.long)
+    for lane in range(64):
+        m, h = lane & 31, lane >> 5
+        for j in range(8):
+            rho = 8 * (j >> 2) + 4 * h + (j & 3)
+            for kb in range(3):
+                k = 32 * kb + m
+                for s_ in range(3):
+                    if s_ < 2:
+                        dd = 16 * s_ + rho
+                    else:
+                        dd = 32 + 4 * h + (j & 3) if j < 4 else 47
+                    kf[kb, s_, lane, j] = k * 48 + dd
+            for db in range(2):
+                dd = 32 * db + m
+                for ks in range(6):
+                    k = 16 * ks + rho
+                    vf[db, ks, lane, j] = k * 48 + (dd if dd < 47 else 47)
+    _XATTN_IDX[key] = (kf.reshape(-1).to(device), vf.reshape(-1).to(device))
+    return _XATTN_IDX[key]
+
+
+def xattn_kv_fragments(k, v):
+    """Text keys / values of one transformer block, k and v [B, nk, 320] (device, bf16, nk <= 96), -> (kf [B, 8 * 9 * 64 * 8],
+    vf [B, 8 * 12 * 64 * 8]) bf16: the MFMA A-operand fragments saspa_xattn_block loads (layouts in include/saspa_hip.h).
+    Time-invariant: built once per generation next to the K / V projections themselves."""
+    b, nk, c = k.shape
+    assert c == XATTN_C and nk <= 96 and tuple(v.shape) == (b, nk, c)
+    ik, iv = _xattn_frag_indices(k.device)
+    kp = torch.zeros((b, XATTN_HEADS, 96, 48), device=k.device, dtype=k.dtype)
+    kp[:, :, :nk, :XATTN_D] = k.reshape(b, nk, XATTN_HEADS, XATTN_D).permute(0, 2, 1, 3)
+    vp = torch.zeros((b, XATTN_HEADS, 96, 48), device=k.device, dtype=k.dtype)
+    vp[:, :, :nk, :XATTN_D] = v.reshape(b, nk, XATTN_HEADS, XATTN_D).permute(0, 2, 1, 3)
+    vp[:, :, :nk, XATTN_D] = 1.0                           # the ones row: the softmax denominator out of the P V product
+    kf = kp.reshape(b, XATTN_HEADS, 96 * 48)[:, :, ik].reshape(b, -1).contiguous()
+    vf = vp.reshape(b, XATTN_HEADS, 96 * 48)[:, :, iv].reshape(b, -1).contiguous()
+    return kf, vf

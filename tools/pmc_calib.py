@@ -9,7 +9,7 @@ Infinity Cache plus the 32 MiB of L2, every row read exactly once by exactly one
 counter applies to this kernel's reads: ~0.5 -> the x2 correction applies, ~1.0 -> the counter is exact.
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/calib_f -- python3 tools/pmc_calib.py
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/calib_w -- python3 tools/pmc_calib.py
-    python3 tools/pmc_calib.py table <fetch csv> <write csv>  > profiles/rN_pmc_calibration.txt"""
+    python3 tools/pmc_calib.py table <fetch csv> <write csv> [<out calibration.json>]  > profiles/rN_pmc_calibration.txt"""
 import csv
 import math
 import os
@@ -33,19 +33,33 @@ if len(sys.argv) > 1 and sys.argv[1] == "table":
         out.sort()
         return out
     fe, wr = rows(sys.argv[2], "FETCH_SIZE"), rows(sys.argv[3], "WRITE_SIZE")
+    factors = {}
     print(f"{'kernel family':46s} {'A + W MB':>9s} {'FETCH raw MB':>13s} {'factor':>7s} {'out MB':>7s} {'WRITE MB':>9s} {'factor':>7s}  correction")
-    # two dispatches per case (the second is measured)
+    # per case: the LAST dispatch of its kernel (each case launches twice, the second after the caches were flushed)
+    def pick(rs, label, conv):
+        fam = label.split(" ")[0]
+        def is_pw(nm):
+            return "<5, true" in nm or "Li5ELb1E" in nm or "ILi5ELb1" in nm
+        cand = [r for r in rs if fam in r[1] and (fam != "gemm_pp_kernel" or is_pw(r[1]) != conv)]
+        return cand[-1] if cand else None
     for i, (label, variant, n, conv) in enumerate(CASES):
-        if 2 * i + 1 >= len(fe) or 2 * i + 1 >= len(wr):
-            break
+        rf, rw = pick(fe, label, conv), pick(wr, label, conv)
+        if rf is None or rw is None:
+            print(f"{label:46s} (did not run)")
+            continue
         mm = (1 << 18) if conv else M                                  # the conv case: 16 images of 128x128
         kk = 9 * K if conv else K
         inb = (mm * K + n * kk) * 2
         outb = mm * n * 2
-        f, w = fe[2 * i + 1][2], wr[2 * i + 1][2]
+        f, w = rf[2], rw[2]
         ff, wf = f / inb, w / outb
         corr = "x2 (reads tallied at half)" if ff < 0.75 else "none (counter exact)"
-        print(f"{label:46s} {inb / 1e6:9.1f} {f / 1e6:13.1f} {ff:7.3f} {outb / 1e6:7.1f} {w / 1e6:9.1f} {wf:7.3f}  {corr}   [{fe[2 * i + 1][1][:40]}]")
+        print(f"{label:46s} {inb / 1e6:9.1f} {f / 1e6:13.1f} {ff:7.3f} {outb / 1e6:7.1f} {w / 1e6:9.1f} {wf:7.3f}  {corr}   [{rf[1][:40]}]")
+        factors[label.split(" ")[0] + (" conv" if conv else "")] = round(ff, 3)
+    if len(sys.argv) > 4:
+        import json
+        # {kernel-name substring: measured FETCH_SIZE / known bytes}; the 3x3 case of the 8-wave kernel is listed for the record
+        json.dump({k.replace(" conv", ""): v for k, v in factors.items() if " conv" not in k}, open(sys.argv[4], "w"), indent=1)
     sys.exit(0)
 
 import torch  # noqa: E402
@@ -64,7 +78,12 @@ for (label, variant, n, conv) in CASES:
         x = torch.randn(M, K, device=dev).to(BF)
         wt = (torch.randn(n, K) / math.sqrt(K)).to(dev, BF)
         f = lambda: ops.linear(x, wt, None, variant=variant, ksplit=1)
-    f()
+    try:
+        f()
+    except RuntimeError as e:            # a family that cannot take this problem: the table says so
+        print(f"{label}: {e}", file=sys.stderr)
+        del x, wt
+        continue
     torch.cuda.synchronize()
     # evict: stream 1 GiB through the caches so that the measured dispatch reads A from HBM
     junk = torch.empty(1 << 30, dtype=torch.uint8, device=dev)

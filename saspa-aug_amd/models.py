@@ -336,13 +336,11 @@ class _Net:
                 self.ctx_kv[t] = (k, vt, n)
 
     # ---- blocks ----
-    def resnet(self, pfx, x, step, eps, x2=None, bslice=None):
+    def resnet(self, pfx, x, step, eps, x2=None):
         p, g = self.p, self.cfg["groups"]
         rv = None
         if pfx in self.temb_tables:
             rv = self.temb_cur_views[pfx] if step is None else self.temb_tables[pfx][step]
-            if bslice is not None and rv.dim() == 2 and rv.shape[0] > 1:
-                rv = rv[bslice]
         h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
         h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv, gn_unit=self.gn_unit)
         h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU)
@@ -365,14 +363,7 @@ class _Net:
         del p[t + ".attn2.q.w"], p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]
         self.fp8_blocks.add(t)
 
-    def _ctx(self, t, bslice):
-        kv = self.ctx_kv[t]
-        if bslice is None:
-            return kv
-        return tuple(e[bslice] if torch.is_tensor(e) else e for e in kv)
-
-    def transformer(self, pfx, x, bslice=None):
-        """bslice: the rows of the hoisted per-sample state (text K / V) this call's batch is (a half batch of a split decoder)."""
+    def transformer(self, pfx, x):
         p, g = self.p, self.cfg["groups"]
         heads, depth = self.tr_info[pfx]
         b, hh, ww, c = x.shape
@@ -406,7 +397,7 @@ class _Net:
                 # W8A8: LayerNorm + per-token quantisation in one pass, e4m3 x e4m3 MFMA, scales applied in the epilogue
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm2.g"], p[t + ".norm2.b"])
                 q = ops.linear_fp8(q8, s8, p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"])
-                k, vtc, nk = self._ctx(t, bslice)[:3]
+                k, vtc, nk = self.ctx_kv[t][:3]
                 o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
@@ -415,7 +406,7 @@ class _Net:
                 h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)
                 continue
             # cross-attention against the cached text K / V^T
-            kv = self._ctx(t, bslice)
+            kv = self.ctx_kv[t]
             if fuse and len(kv) == 5 and n % 256 == 0 and kv[2] <= 96:
                 # level 0 of a full-size batch: LayerNorm + to_q + attention + to_out + residual in one launch
                 h = ops.xattn_block(h, (p[t + ".norm2.g"], p[t + ".norm2.b"], 1e-5), p[t + ".attn2.xw"], p[t + ".attn2.xb"], kv[3], kv[4],
@@ -495,52 +486,21 @@ class UNet(_Net):
         pk.conv("conv_out")
         pk.sd = None  # drop the fp32 host copy reference
 
-    def _decode_levels(self, s, skips, step, lvl0, lvl1, bslice=None, out_last=None):
-        """Up blocks [lvl0, lvl1) on s with `skips` (consumed from the end).  out_last: where the last of these levels' upsampler
-        writes (a view of a joined tensor)."""
-        cfg, p = self.cfg, self.p
-        n_lvl = len(cfg["block_out"])
-        rev_attn = list(reversed(cfg["attn"]))
-        for i in range(lvl0, lvl1):
-            for j in range(cfg["layers"] + 1):
-                sk = skips.pop()
-                s = self.resnet(f"up_blocks.{i}.resnets.{j}", s, step, 1e-5, x2=sk, bslice=bslice)
-                if rev_attn[i]:
-                    s = self.transformer(f"up_blocks.{i}.attentions.{j}", s, bslice=bslice)
-            if i != n_lvl - 1:
-                u = f"up_blocks.{i}.upsamplers.0.conv"
-                s = ops.conv(s, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True, gn_unit=self.gn_unit,
-                             out=out_last if i == lvl1 - 1 else None)
-        return s
-
-    def decode(self, mid, skips, step, out=None, split_levels=0, side=None):
-        """split_levels = k > 0 with a side stream: the k deepest up blocks (8x8, 16x16, ... levels: small, chip-underfilling
-        launches) run as TWO half-batch paths side by side -- the CFG halves are independent samples -- each sized for a shared
-        chip (ops.twin_branch), joined in the tensor the last of these levels' upsampler writes.  Same arithmetic per sample;
-        results differ from the unsplit order only where a split-K choice changes the summation order."""
+    def decode(self, mid, skips, step, out=None):
         cfg, p = self.cfg, self.p
         s = mid
         skips = list(skips)
         n_lvl = len(cfg["block_out"])
-        b = mid.shape[0]
-        k = min(int(split_levels), n_lvl - 1)           # the last level ends in conv_out, not in an upsampler: never split
-        if k > 0 and side is not None and b % 2 == 0 and b >= 4:
-            half = b // 2
-            npop = k * (cfg["layers"] + 1)
-            region, skips = skips[len(skips) - npop:], skips[:len(skips) - npop]
-            c_out = list(reversed(cfg["block_out"]))[k - 1]
-            joined = torch.empty((b, mid.shape[1] << k, mid.shape[2] << k, ops.round8(c_out)), device=mid.device, dtype=mid.dtype)
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            with ops.twin_branch(True):
-                with torch.cuda.stream(side):
-                    self._decode_levels(mid[half:], [t[half:] for t in region], step, 0, k, slice(half, b), joined[half:])
-                self._decode_levels(mid[:half], [t[:half] for t in region], step, 0, k, slice(0, half), joined[:half])
-            main.wait_stream(side)
-            s = joined
-            s = self._decode_levels(s, skips, step, k, n_lvl)
-        else:
-            s = self._decode_levels(s, skips, step, 0, n_lvl)
+        rev_attn = list(reversed(cfg["attn"]))
+        for i in range(n_lvl):
+            for j in range(cfg["layers"] + 1):
+                sk = skips.pop()
+                s = self.resnet(f"up_blocks.{i}.resnets.{j}", s, step, 1e-5, x2=sk)
+                if rev_attn[i]:
+                    s = self.transformer(f"up_blocks.{i}.attentions.{j}", s)
+            if i != n_lvl - 1:
+                u = f"up_blocks.{i}.upsamplers.0.conv"
+                s = ops.conv(s, p[u + ".w"], p[u + ".b"], kh=3, kw=3, pad=1, upsample=True, gn_unit=self.gn_unit)
         s = ops.groupnorm(s, p["conv_norm_out.g"], p["conv_norm_out.b"], cfg["groups"], 1e-5, SILU)
         return ops.conv(s, p["conv_out.w"], p["conv_out.b"], kh=3, kw=3, pad=1, out=out)
 

@@ -46,11 +46,6 @@ def fork_enabled():
     return os.environ.get("SASPA_FORK", "1") != "0"
 
 
-def decoder_split_levels():
-    """How many of the deepest UNet decoder levels run as two half-batch graph paths (SASPA_DECODER_SPLIT; 0 = none)."""
-    return int(os.environ.get("SASPA_DECODER_SPLIT", "0"))
-
-
 class _StepGraph:
     """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM or PLMS update,
     ~1 500 kernel nodes -- replayed once per network evaluation.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
@@ -151,11 +146,7 @@ class _StepGraph:
         else:
             mid, skips = pipe.unet.encode(x, None)
             skips2, mid2 = pipe.controlnet.forward(x, None, self.cemb, self.cscale, skips, mid)
-        if pipe.controlnet is not None and fork_enabled() and ops._RECORDER is None and decoder_split_levels() > 0:
-            # the deepest decoder levels as two half-batch graph paths (models.UNet.decode)
-            pipe.unet.decode(mid2, skips2, None, out=self.eps, split_levels=decoder_split_levels(), side=self.side)
-        else:
-            pipe.unet.decode(mid2, skips2, None, out=self.eps)
+        pipe.unet.decode(mid2, skips2, None, out=self.eps)
         nimg = x.shape[0] // 2 if self.cfg else x.shape[0]
         nc, hw = pipe.cfgs["unet"]["out_channels"], x.shape[1] * x.shape[2]
         if self.unipc and self.cfg:

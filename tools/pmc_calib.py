@@ -53,7 +53,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "table":
         outb = mm * n * 2
         f, w = rf[2], rw[2]
         ff, wf = f / inb, w / outb
-        corr = "x2 (reads tallied at half)" if ff < 0.75 else "none (counter exact)"
+        if conv:
+            corr = "x2 + halo rows re-fetched beyond L2 (not a clean calibration: its true bytes are not known by construction)"
+        else:
+            corr = "x2 (reads tallied at half)" if ff < 0.75 else "none (counter exact)"
         print(f"{label:46s} {inb / 1e6:9.1f} {f / 1e6:13.1f} {ff:7.3f} {outb / 1e6:7.1f} {w / 1e6:9.1f} {wf:7.3f}  {corr}   [{rf[1][:40]}]")
         factors[label.split(" ")[0] + (" conv" if conv else "")] = round(ff, 3)
     if len(sys.argv) > 4:

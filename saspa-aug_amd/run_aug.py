@@ -204,6 +204,21 @@ def read_prompts(prompts_file):
     return prompts
 
 
+def read_prompts_from_json(json_file, dataset_name=None, per_class=False):
+    """prompts_engineering/blip_utils.py:14-27: a {class: [prompts]} JSON -> the dict itself (per_class) or every class's
+    prompts in file order (PROMPT_TYPE "txt2sentence-per_class" / "txt2sentence", run_aug/run_aug.py:331-339); truncated to
+    MAX_PROMPT_LENGTH like the reference does after reading."""
+    import json as _json
+    with open(json_file, "r") as f:
+        d = _json.load(f)
+    if per_class:
+        return {k: [q[:MAX_PROMPT_LENGTH] for q in v] for k, v in d.items()}
+    out = []
+    for v in d.values():
+        out += v
+    return [q[:MAX_PROMPT_LENGTH] for q in out]
+
+
 # ------------------------------------------------------------------------------------------
 # pipeline construction / call (run_aug/run_aug.py:128-279)
 # ------------------------------------------------------------------------------------------
@@ -364,14 +379,31 @@ def decorate_prompt(s: Settings, prompt, i, image_stem, source_image_path, image
 def default_prompts_file(s: Settings):
     """The prompt source the reference's config block selects per dataset (run_aug/run_aug.py:589-666) for
     PROMPT_TYPE "gpt-meta_class" (100 GPT-written prompts per meta class, shipped as data next to this module) or
-    "captions" (per-image BLIP captions: DTD only)."""
+    "captions" (per-image BLIP captions: DTD only), and for the baseline prompt sources "ALIA" / "txt2sentence" /
+    "txt2sentence-per_class" where the reference ships the file."""
     here = Path(__file__).parent / "prompts_engineering"
     if s.PROMPT_TYPE == "captions":
         if s.DATASET != "dtd":
             raise NotImplementedError(f"no caption file ships for {s.DATASET} (the reference has dtd_captions.json only)")
         return str(here / "captions" / "dtd_captions.json")
+    if s.PROMPT_TYPE == "ALIA":
+        # run_aug/run_aug.py:665-666 (the reference forgets the f-string prefix there; the files it means ship with it)
+        f = here / "ALIA_prompts" / "gpt_output" / f"{'planes' if s.DATASET == 'synthetic' else s.DATASET}_prompts.txt"
+        if not f.exists():
+            raise NotImplementedError(f"no ALIA prompt file for {s.DATASET}")
+        return str(f)
+    if s.PROMPT_TYPE in ("txt2sentence", "txt2sentence-per_class"):
+        # run_aug/run_aug.py:592-660 names LE_{200,30}_{dataset}_all_classes_{False,True}.json; the reference ships only the
+        # cars txt2sentence file (under prompts_engineering/txt2sentance_prompts): anything else comes through PROMPTS_FILE
+        ds = {"compcars-parts": "cars", "planes_biased": "planes"}.get(s.DATASET, s.DATASET)
+        name = f"LE_30_{ds}_all_classes_True.json" if s.PROMPT_TYPE.endswith("per_class") else f"LE_200_{ds}_all_classes_False.json"
+        f = here / "txt2sentance_prompts" / name
+        if not f.exists():
+            raise NotImplementedError(f"{s.PROMPT_TYPE}: {name} does not ship with the reference; pass Settings.PROMPTS_FILE "
+                                      "(a {class: [prompts]} JSON written by prompts_engineering/txt2sentance_prompts.py)")
+        return str(f)
     if s.PROMPT_TYPE != "gpt-meta_class":
-        raise NotImplementedError(f"PROMPT_TYPE {s.PROMPT_TYPE}: txt2sentence / ALIA prompt sets are baseline branches")
+        raise NotImplementedError(f"PROMPT_TYPE {s.PROMPT_TYPE}")
     name = {"planes": "planes", "planes_biased": "planes", "synthetic": "planes", "cars": "cars", "compcars-parts": "cars",
             "cub": "cub"}.get(s.DATASET)
     if name is None:
@@ -380,7 +412,7 @@ def default_prompts_file(s: Settings):
 
 
 def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None,
-              same_class_fn=None, ds_utils=None, captions=None):
+              same_class_fn=None, ds_utils=None, captions=None, class_to_prompts=None):
     """Returns the work items in the reference's loop order.  Must be called right after
     utils.set_seed(SEED) (and dataset construction), like the reference's loop."""
     if image_size_fn is None:
@@ -407,6 +439,9 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
         if s.PROMPT_TYPE == "captions":                                      # :361-363 the image's own BLIP caption, N times
             cap = captions[source_image_path]["caption"][:MAX_PROMPT_LENGTH]
             prompts = [cap[:-1] if cap and cap[-1] == "." else cap] * s.NUM_PER_IMAGE
+        elif s.PROMPT_TYPE == "txt2sentence-per_class":                        # :365-367 the prompts of the image's own class
+            key = image_stem if s.DATASET in ("planes", "cars", "planes_biased", "synthetic") else source_image_path
+            prompts = [q[:-1] if q and q[-1] == "." else q for q in class_to_prompts[image_classes_dict[key]]]
         sampled = np.random.choice(prompts, s.NUM_PER_IMAGE)                 # :382
         for i, prompt in enumerate(sampled):
             prompt = decorate_prompt(s, str(prompt), i, image_stem, source_image_path, image_classes_dict, ds_utils)
@@ -600,14 +635,21 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     if rank == 0:
         utils.init_logging(str(Path(output_folder).parent))
     image_classes_dict = ds_utils.get_image_stem_to_class_str_dict()     # path-keyed for dtd / cub / compcars-parts (:700)
-    captions = None
+    captions, class_to_prompts = None, None
     if s.PROMPT_TYPE == "captions":
         import json as _json
         with open(prompts_file, "r") as f:
             captions = _json.load(f)
         prompts = None
         logging.info(f"Read {len(captions)} captions from {prompts_file}")
-    else:
+    elif s.PROMPT_TYPE == "txt2sentence-per_class":
+        class_to_prompts = read_prompts_from_json(prompts_file, s.DATASET, per_class=True)
+        prompts = None
+        logging.info(f"Read prompts json with {len(class_to_prompts)} classes from {prompts_file}")
+    elif s.PROMPT_TYPE == "txt2sentence":
+        prompts = read_prompts_from_json(prompts_file, s.DATASET, per_class=False)
+        logging.info(f"Read {len(prompts)} prompts from {prompts_file}")
+    else:                                           # gpt-meta_class, ALIA: one prompt per line
         prompts = read_prompts(prompts_file)
         logging.info(f"Read {len(prompts)} prompts from {prompts_file}")
     aug_json_path = utils.get_aug_json_path(output_folder, semantic_filtering=s.SEMANTIC_FILTERING,
@@ -622,7 +664,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     blip = "blip_diffusion" in s.BASE_MODEL
     items = plan_work(s, ds_utils.original_images_paths, prompts, output_folder, image_classes_dict,
                       same_class_fn=ds_utils.get_image_path_with_same_class if blip else None, ds_utils=ds_utils,
-                      captions=captions)
+                      captions=captions, class_to_prompts=class_to_prompts)
     mine = shard_items(items, world)[rank]
     logging.info(f"rank {rank}/{world}: {len(mine)} of {len(items)} work items ({sum(i.skip for i in items)} already exist)")
 

@@ -106,6 +106,10 @@ template <> struct Elem<f32x3_t> {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// SiLU for values that are rounded to bf16 right after: v_exp_f32 + v_rcp_f32 (each within 1 ulp of fp32) instead of expf's
+// range handling and the IEEE division sequence (~16 VALU per element -> 5): the GroupNorm apply pass was VALU-bound on it
+// (2.4 TB/s on every size, tools/gn_bench.py).  The fp32 parity path keeps silu_f.
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // activation applied BEFORE the residual add (SiLU, ReLU) / AFTER it (ReLU of ResNet bottlenecks); see saspa_hip.h
 __device__ __forceinline__ float act_pre(int act, float x) {
   return act == SASPA_ACT_SILU ? silu_f(x) : (act == SASPA_ACT_RELU ? fmaxf(x, 0.0f) : x);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float y = v[j] * scv[j] + shv[j];
-      if (silu) y = silu_f(y);
+      if (silu) y = sizeof(T) == 2 ? silu_fast(y) : silu_f(y);
       v[j] = y;
     }
     T* dst = reinterpret_cast<T*>(p.y) + pix * p.ldy + ch;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const SaspaGroupNormParam
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float y = v[u][j] * scv[j] + shv[j];
-        if (silu) y = silu_f(y);
+        if (silu) y = sizeof(T) == 2 ? silu_fast(y) : silu_f(y);
         v[u][j] = y;
       }
       T* dst = reinterpret_cast<T*>(p.y) + ((long long)b * p.hw + px + u * rows) * p.ldy + ch;

@@ -38,5 +38,5 @@ for (b, h, w, c, c2) in ((16, 64, 64, 320, 0), (16, 64, 64, 320, 320), (16, 64, 
     t2 = timeit(fused)
     os.environ["SASPA_GN_FUSE"] = "1"
     mb = 2 * b * h * w * ct * 2 / 1e6
-    
+    print(f"GN+SiLU [{b},{h},{w},{c}{'+' + str(c2) if c2 else ''}] {mb:6.1f} MB r+w: epilogue statistics{'' if has else ' (n/a)'} {tf:6.1f} us = {mb / tf:5.2f} TB/s | "
           f"statistics pass + apply {t2:6.1f} us", flush=True)

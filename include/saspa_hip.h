@@ -226,6 +226,12 @@ typedef struct SaspaGroupNormParams {
 } SaspaGroupNormParams;
 int saspa_groupnorm_stats(const SaspaGroupNormParams* p, void* stream);
 int saspa_groupnorm_apply(const SaspaGroupNormParams* p, void* stream);
+/* ABI 17: statistics + apply in ONE launch for small images (one workgroup per (image, group): the group's hw * C / groups
+ * values are read once into registers, reduced, normalised and written) -- the 8x8 level of the UNet / ControlNet, where a
+ * GroupNorm was two launches of launch latency.  `partial` / `nsplit` / `stats*` are not read.  _eligible: non-zero when every
+ * group lies inside one source, has whole 8-channel chunks and hw * (C / groups) <= 8 192. */
+int saspa_groupnorm_onepass_eligible(const SaspaGroupNormParams* p);
+int saspa_groupnorm_onepass(const SaspaGroupNormParams* p, void* stream);
 
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, CLIP LNs). */
 int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int C,

@@ -115,6 +115,8 @@ SYMBOLS = {
     "saspa_cfg_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, _F, C.POINTER(C.c_float), _P, _P, _P]),
     "saspa_unipc_step": (_I, [_I, _P, _P, _P, _I, _LL, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
     "saspa_xattn_block": (_I, [C.POINTER(XattnBlockParams), _P]),
+    "saspa_groupnorm_onepass_eligible": (_I, [C.POINTER(GroupNormParams)]),
+    "saspa_groupnorm_onepass": (_I, [C.POINTER(GroupNormParams), _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

@@ -371,7 +371,112 @@ int check_gn(const SaspaGroupNormParams& p) {
   return 0;
 }
 
+// ---- small images: statistics + apply in ONE launch ------------------------------------------------------------------
+// At the 8x8 level (hw = 64: no 128-row statistics blocks, so no epilogue statistics either) a GroupNorm was two launches of a
+// few microseconds of work each -- 24 pairs per UNet + ControlNet evaluation, all launch latency.  Here one workgroup owns one
+// (image, group): its hw x cpg values (64 x 40 = 5 KB at the 8x8 level) are read ONCE into registers, reduced over the workgroup
+// (fp32 partial sums per thread, fp64 combine), normalised from the registers and written: one read, one write, one launch.
+// items = hw * cpg / 8 chunks of 8 channels, at most GN1_ITEMS per thread.
+constexpr int GN1_ITEMS = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_onepass_kernel(const SaspaGroupNormParams p) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int C = p.c0 + p.c1;
+  const int cpg = C / p.groups, cp8 = cpg >> 3;
+  const int ch0 = g * cpg;
+  const T* src;
+  int ld, cc;
+  if (ch0 < p.c0) { src = reinterpret_cast<const T*>(p.x0); ld = p.ldx0; cc = ch0; }     // a group lies inside ONE source (host checks)
+  else { src = reinterpret_cast<const T*>(p.x1); ld = p.ldx1; cc = ch0 - p.c0; }
+  const int items = p.hw * cp8;
+  float v[GN1_ITEMS][8];
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN1_ITEMS; ++i) {
+    const int it = tid + i * 256;
+    if (it < items) {
+      const int px = it / cp8, c8 = it - px * cp8;
+      const T* ptr = src + ((long long)b * p.hw + px) * ld + cc + c8 * 8;
+      if constexpr (sizeof(T) == 2) {
+        Elem<T>::load_chunk(ptr, v[i]);
+      } else {
+        Elem<T>::load_chunk(ptr, v[i]);
+        Elem<T>::load_chunk(ptr + 4, v[i] + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sm += v[i][j]; sq += v[i][j] * v[i][j]; }
+    }
+  }
+  double dsm = (double)sm, dsq = (double)sq;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dsm += __shfl_xor(dsm, o, 64);
+    dsq += __shfl_xor(dsq, o, 64);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = dsm; red[1][tid >> 6] = dsq; }
+  __syncthreads();
+  const double n = (double)cpg * (double)p.hw;
+  const double mean_d = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+  double var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const bool silu = p.act == SASPA_ACT_SILU;
+#pragma unroll
+  for (int i = 0; i < GN1_ITEMS; ++i) {
+    const int it = tid + i * 256;
+    if (it < items) {
+      const int px = it / cp8, c8 = it - px * cp8;
+      const int ch = ch0 + c8 * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sc = p.gamma[ch + j] * rstd;
+        float y = v[i][j] * sc + (p.beta[ch + j] - mean * sc);          // the arithmetic of gn_apply_kernel
+        if (silu) y = sizeof(T) == 2 ? silu_fast(y) : silu_f(y);
+        v[i][j] = y;
+      }
+      T* dst = reinterpret_cast<T*>(p.y) + ((long long)b * p.hw + px) * p.ldy + ch;
+      if constexpr (sizeof(T) == 2) {
+        Elem<T>::store_chunk(dst, v[i]);
+      } else {
+        Elem<T>::store_chunk(dst, v[i]);
+        Elem<T>::store_chunk(dst + 4, v[i] + 4);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// One-launch GroupNorm (ABI 17): eligible when a group lies inside one source, has whole 8-channel chunks and its hw * cpg values
+// fit one workgroup's registers (hw * cpg <= 256 * GN1_ITEMS * 8 = 8 192: 8x8 ... 8x12 pixel levels at 40 - 80 channels per group).
+extern "C" int saspa_groupnorm_onepass_eligible(const SaspaGroupNormParams* pp) {
+  if (!pp) return 0;
+  const SaspaGroupNormParams& p = *pp;
+  const int C = p.c0 + p.c1;
+  if (p.groups <= 0 || C % p.groups) return 0;
+  const int cpg = C / p.groups;
+  if (cpg % 8 || (p.c1 > 0 && p.c0 % cpg) || (long long)p.hw * cpg > 256LL * GN1_ITEMS * 8) return 0;
+  return 1;
+}
+
+extern "C" int saspa_groupnorm_onepass(const SaspaGroupNormParams* pp, void* stream) {
+  if (!pp) return SASPA_EINVAL;
+  const SaspaGroupNormParams& p = *pp;
+  if (!p.x0 || !p.gamma || !p.beta || !p.y || p.batch <= 0 || p.hw <= 0 || p.groups <= 0) return SASPA_EINVAL;
+  if (p.c1 > 0 && !p.x1) return SASPA_EINVAL;
+  if (p.dtype != SASPA_BF16 && p.dtype != SASPA_F32) return SASPA_EINVAL;
+  if (p.c0 % 8 || p.c1 % 8 || p.ldx0 % 8 || (p.c1 > 0 && p.ldx1 % 8) || p.ldy % 8) return SASPA_EALIGN;
+  if (!aligned16(p.x0) || (p.x1 && !aligned16(p.x1)) || !aligned16(p.y)) return SASPA_EALIGN;
+  if (p.batch > 65535 || !saspa_groupnorm_onepass_eligible(pp)) return SASPA_ERANGE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(p.groups, p.batch);
+  if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_onepass_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gn_onepass_kernel<float>, grid, dim3(256), 0, s, p);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int saspa_groupnorm_stats(const SaspaGroupNormParams* pp, void* stream) {
   if (!pp) return SASPA_EINVAL;

@@ -158,6 +158,11 @@ def _as_over_stats():
     return os.environ.get("SASPA_GEMM_AS_OVER_STATS", "1") != "0"
 
 
+def gn_onepass_enabled():
+    """SASPA_GN_ONEPASS=0: small-image GroupNorms run as statistics pass + apply pass again (A/B knob)."""
+    return os.environ.get("SASPA_GN_ONEPASS", "1") != "0"
+
+
 def gn_fusion_enabled():
     """SASPA_GN_FUSE=0: every GroupNorm runs its own statistics pass (A/B knob for the epilogue statistics)."""
     return os.environ.get("SASPA_GN_FUSE", "1") != "0"
@@ -472,6 +477,20 @@ def groupnorm(x, gamma, beta, groups, eps, act=ACT_NONE, x2=None, out=None):
         p.stats0, p.stats1, p.unit = _ptr(g0[0]), (_ptr(g1[0]) if g1 is not None else None), g0[1]
         _lib.check(lib.saspa_groupnorm_apply(C.byref(p), _stream()), "saspa_groupnorm_apply(epilogue statistics)")
         return out
+    if gn_onepass_enabled():
+        # small images (the 8x8 level: no 128-row statistics blocks): statistics + apply in one launch
+        p = _lib.GroupNormParams()
+        p.dtype = _dt(x)
+        p.x0, p.x1, p.c0, p.c1 = _ptr(x), _ptr(x2), c0, c1
+        p.ldx0 = _pitch4(x)
+        p.ldx1 = 0 if x2 is None else _pitch4(x2)
+        p.batch, p.hw, p.groups, p.eps = b, h * w, groups, float(eps)
+        p.gamma, p.beta = _ptr(gamma), _ptr(beta)
+        p.partial, p.nsplit, p.scale_shift = None, 0, None
+        p.act, p.y, p.ldy = int(act), _ptr(out), _pitch4(out)
+        if lib.saspa_groupnorm_onepass_eligible(C.byref(p)):
+            _lib.check(lib.saspa_groupnorm_onepass(C.byref(p), _stream()), "saspa_groupnorm_onepass")
+            return out
     nsplit = _gn_nsplit(b, h * w, ctot // 8)
     partial = torch.empty((b * nsplit * ctot * 2,), device=x.device, dtype=torch.float32)
     p = _lib.GroupNormParams()

@@ -396,6 +396,38 @@ def test_groupnorm(dev, dtype, b, h, w_, c, groups, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,w_,c0,c1,groups,act", [(16, 8, 8, 1280, 0, 32, 1), (16, 8, 8, 1280, 1280, 32, 1), (2, 8, 11, 1280, 0, 32, 0),
+                                                     (3, 8, 12, 2560, 0, 32, 1), (2, 4, 4, 640, 640, 32, 1)])
+def test_groupnorm_onepass(dev, dtype, b, h, w_, c0, c1, groups, act, monkeypatch):
+    """saspa_groupnorm_onepass (ABI 17): the 8x8-level GroupNorms (hw * channels-per-group <= 8 192) as one launch -- against
+    torch and against the two-launch form of the same kernel family (SASPA_GN_ONEPASS=0)."""
+    x0 = q(_rand(b, c0, h, w_, seed=41) * 2 + 0.5, dtype)
+    x1 = q(_rand(b, c1, h, w_, seed=42) * 3 - 0.2, dtype) if c1 else None
+    c = c0 + c1
+    g, be = 1 + 0.1 * _rand(c, seed=43), 0.1 * _rand(c, seed=44)
+    ref = F.group_norm(x0 if x1 is None else torch.cat([x0, x1], 1), groups, g, be, 1e-5)
+    if act:
+        ref = F.silu(ref)
+    a0, a1 = to_nhwc(x0, dtype, dev), (to_nhwc(x1, dtype, dev) if c1 else None)
+    p = _lib_gn_params(a0, a1, b, h * w_, groups)
+    assert ops._lib.load().saspa_groupnorm_onepass_eligible(p) == 1
+    out = ops.groupnorm(a0, g.to(dev), be.to(dev), groups, 1e-5, act, x2=a1)
+    assert_close(from_nhwc(out), ref, dtype, what="groupnorm one-pass")
+    monkeypatch.setenv("SASPA_GN_ONEPASS", "0")
+    two = ops.groupnorm(a0, g.to(dev), be.to(dev), groups, 1e-5, act, x2=a1)
+    d = (out.float() - two.float()).abs().max().item()
+    assert d <= (2e-2 if dtype == torch.bfloat16 else 2e-5) * max(1.0, ref.abs().max().item()), d
+
+
+def _lib_gn_params(a0, a1, b, hw, groups):
+    import ctypes
+    p = ops._lib.GroupNormParams()
+    p.c0, p.c1 = a0.shape[-1], 0 if a1 is None else a1.shape[-1]
+    p.batch, p.hw, p.groups = b, hw, groups
+    return ctypes.byref(p)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_groupnorm_concat(dev, dtype):
     b, h, w_, c0, c1, groups = 2, 8, 8, 64, 32, 8
     x0, x1 = q(_rand(b, c0, h, w_, seed=31), dtype), q(_rand(b, c1, h, w_, seed=32) * 3, dtype)

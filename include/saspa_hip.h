@@ -152,6 +152,10 @@ typedef struct SaspaGemmParams {
    * slices with fp32 slabs and a reduce launch, the 16x16 level takes two slices instead of four.  Only saspa_gemm_suggest_ksplit
    * and the AUTO dispatch read it; the result differs from sharing = 0 by the summation order of K only. */
   int sharing;
+  /* ABI 18.  1: when the launch runs on K slices (ksplit > 1 with a workspace), saspa_gemm leaves the fp32 partial slabs in
+   * `workspace` and does NOT run its reduce / epilogue launch -- the caller hands them to saspa_splitk_groupnorm, which sums
+   * them, adds bias / row vector and applies the consuming GroupNorm in the same launch (`out` is then not written). */
+  int defer_reduce;
 } SaspaGemmParams;
 /* Non-zero if the A-stationary kernel can run the problem (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at least 192
  * blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or fused GEGLU,
@@ -232,6 +236,16 @@ int saspa_groupnorm_apply(const SaspaGroupNormParams* p, void* stream);
  * group lies inside one source, has whole 8-channel chunks and hw * (C / groups) <= 8 192. */
 int saspa_groupnorm_onepass_eligible(const SaspaGroupNormParams* p);
 int saspa_groupnorm_onepass(const SaspaGroupNormParams* p, void* stream);
+/* ABI 18: split-K reduce + epilogue + GroupNorm(+SiLU) in ONE launch for small images: ResnetBlock2D.conv1 -> norm2 -> SiLU at
+ * the 8x8 / 16x16 levels, where conv1 runs on K slices and its reduce launch, the GroupNorm statistics and the apply pass were
+ * three launches of launch latency around a tensor nobody else reads.  g: the conv's parameters as given to saspa_gemm with
+ * defer_reduce = 1 (M, N, hout * wout rows per image, workspace, ksplit, bias, rowvec / ldrv, alpha; no activation, no residual);
+ * n: the GroupNorm (batch, hw, groups, eps, gamma, beta, act, y / ldy; one source of N channels).  One workgroup per (image,
+ * group) sums the slabs of its hw x N / groups values, rounds them to the storage dtype (the rounding point of the unfused path),
+ * takes the statistics, normalises from registers and writes y.  _eligible: non-zero if (N / groups) % 4 == 0 and
+ * hw * N / groups <= 12 288. */
+int saspa_splitk_groupnorm_eligible(const SaspaGemmParams* g, const SaspaGroupNormParams* n);
+int saspa_splitk_groupnorm(const SaspaGemmParams* g, const SaspaGroupNormParams* n, void* stream);
 
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, CLIP LNs). */
 int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int C,

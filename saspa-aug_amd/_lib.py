@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
         ("so1", C.c_longlong), ("so2", C.c_longlong), ("ksplit", C.c_int), ("workspace", C.c_void_p),
         ("variant", C.c_int), ("korder", C.c_int), ("gn_stats", C.c_void_p), ("gn_unit", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("out_t", C.c_void_p), ("ldt", C.c_int),
-        ("st", C.c_longlong), ("n_split", C.c_int), ("rows_per_batch", C.c_int), ("sharing", C.c_int),
+        ("st", C.c_longlong), ("n_split", C.c_int), ("rows_per_batch", C.c_int), ("sharing", C.c_int), ("defer_reduce", C.c_int),
     ]
 
 
@@ -117,6 +117,8 @@ SYMBOLS = {
     "saspa_xattn_block": (_I, [C.POINTER(XattnBlockParams), _P]),
     "saspa_groupnorm_onepass_eligible": (_I, [C.POINTER(GroupNormParams)]),
     "saspa_groupnorm_onepass": (_I, [C.POINTER(GroupNormParams), _P]),
+    "saspa_splitk_groupnorm_eligible": (_I, [C.POINTER(GemmParams), C.POINTER(GroupNormParams)]),
+    "saspa_splitk_groupnorm": (_I, [C.POINTER(GemmParams), C.POINTER(GroupNormParams), _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

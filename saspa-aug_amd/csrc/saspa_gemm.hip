@@ -1264,6 +1264,7 @@ int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles
 }
 
 int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
+  if (p.defer_reduce) return 0;      // ABI 18: the slabs go to saspa_splitk_groupnorm
   if (p.gn_stats) {        // saspa_gemm checked: bf16, N % 160 == 0, 160 % gn_unit == 0
     hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((p.M + 127) / 128, p.N / 80), dim3(256), 0, s, p, ksplit);
     SASPA_CHECK_LAUNCH();

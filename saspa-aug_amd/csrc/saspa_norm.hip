@@ -447,6 +447,107 @@ __global__ __launch_bounds__(256) void gn_onepass_kernel(const SaspaGroupNormPar
   }
 }
 
+// ---- split-K reduce + epilogue + GroupNorm(+SiLU) in one launch (ABI 18) ----------------------------------------------
+// One workgroup per (image, group): item = one float4 (4 channels) of one pixel, hw * cpg / 4 items, at most SKGN_ITEMS per thread
+// kept in registers between the statistics and the apply.
+constexpr int SKGN_ITEMS = 12;
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_gn_kernel(const SaspaGemmParams gp, const SaspaGroupNormParams p) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int N = gp.N;
+  const int cpg = N / p.groups, c4 = cpg >> 2;
+  const int ch0 = g * cpg;
+  const int items = p.hw * c4;
+  const long long slab = (long long)gp.M * N;
+  const int ks = gp.ksplit;
+  float v[SKGN_ITEMS][4];
+  float sm = 0.f, sq = 0.f;
+  // slab-outer, item-inner: the SKGN_ITEMS loads of one slab are independent and in flight together (an item-outer loop would
+  // serialise ks dependent load latencies per item)
+  int off[SKGN_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SKGN_ITEMS; ++i) {
+    const int it = tid + i * 256;
+    const int px = it / c4, q = it - px * c4;
+    off[i] = it < items ? (b * p.hw + px) * N + ch0 + q * 4 : -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = 0.f;
+  }
+  for (int s_ = 0; s_ < ks; ++s_) {
+    const float* src = gp.workspace + s_ * slab;
+    float4 c[SKGN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SKGN_ITEMS; ++i)
+      if (off[i] >= 0) c[i] = *reinterpret_cast<const float4*>(src + off[i]);
+#pragma unroll
+    for (int i = 0; i < SKGN_ITEMS; ++i)
+      if (off[i] >= 0) { v[i][0] += c[i].x; v[i][1] += c[i].y; v[i][2] += c[i].z; v[i][3] += c[i].w; }
+  }
+#pragma unroll
+  for (int i = 0; i < SKGN_ITEMS; ++i) {
+    if (off[i] >= 0) {
+      const int it = tid + i * 256;
+      const int px = it / c4, q = it - px * c4;
+      const int n = ch0 + q * 4;
+      float t[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+      if (gp.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(gp.bias + n);
+        t[0] += b4.x; t[1] += b4.y; t[2] += b4.z; t[3] += b4.w;
+      }
+      if (gp.rowvec) {
+        const float4 r4 = *reinterpret_cast<const float4*>(gp.rowvec + (long long)b * gp.ldrv + n);
+        t[0] += r4.x; t[1] += r4.y; t[2] += r4.z; t[3] += r4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = t[j] * gp.alpha;
+        if constexpr (sizeof(T) == 2) {            // the value the unfused path stores (and its GroupNorm reads back): bf16
+          const unsigned w2 = pack2(x, 0.f);
+          x = __builtin_bit_cast(float, w2 << 16);
+        }
+        v[i][j] = x;
+        sm += x;
+        sq += x * x;
+      }
+    }
+  }
+  double dsm = (double)sm, dsq = (double)sq;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dsm += __shfl_xor(dsm, o, 64);
+    dsq += __shfl_xor(dsq, o, 64);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = dsm; red[1][tid >> 6] = dsq; }
+  __syncthreads();
+  const double cnt = (double)cpg * (double)p.hw;
+  const double mean_d = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / cnt;
+  double var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / cnt - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const bool silu = p.act == SASPA_ACT_SILU;
+#pragma unroll
+  for (int i = 0; i < SKGN_ITEMS; ++i) {
+    const int it = tid + i * 256;
+    if (it < items) {
+      const int px = it / c4, q = it - px * c4;
+      const int n = ch0 + q * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + n), b4 = *reinterpret_cast<const float4*>(p.beta + n);
+      const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+      float y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = gm[j] * rstd;
+        float o = v[i][j] * sc + (bt[j] - mean * sc);                   // the arithmetic of gn_apply_kernel
+        if (silu) o = sizeof(T) == 2 ? silu_fast(o) : silu_f(o);
+        y[j] = o;
+      }
+      Elem<T>::store4(reinterpret_cast<T*>(p.y) + ((long long)b * p.hw + px) * p.ldy + n, y);
+    }
+  }
+}
+
 }  // namespace
 
 // One-launch GroupNorm (ABI 17): eligible when a group lies inside one source, has whole 8-channel chunks and its hw * cpg values
@@ -474,6 +575,40 @@ extern "C" int saspa_groupnorm_onepass(const SaspaGroupNormParams* pp, void* str
   dim3 grid(p.groups, p.batch);
   if (p.dtype == SASPA_BF16) hipLaunchKernelGGL(gn_onepass_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_onepass_kernel<float>, grid, dim3(256), 0, s, p);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int saspa_splitk_groupnorm_eligible(const SaspaGemmParams* gp, const SaspaGroupNormParams* np) {
+  if (!gp || !np) return 0;
+  const SaspaGemmParams& g = *gp;
+  const SaspaGroupNormParams& p = *np;
+  if (p.groups <= 0 || g.N <= 0 || g.N % p.groups) return 0;
+  const int cpg = g.N / p.groups;
+  if (cpg % 4 || (long long)p.hw * cpg > 256LL * SKGN_ITEMS * 4 || (long long)g.M * g.N >= (1LL << 31)) return 0;
+  if (g.residual || g.act != SASPA_ACT_NONE || (long long)g.nb1 * g.nb2 > 1 || g.gn_stats) return 0;
+  if ((long long)p.batch * p.hw != g.M || p.hw != g.hout * g.wout || p.c0 != g.N || p.c1 != 0) return 0;
+  if (g.dtype != SASPA_BF16 && g.dtype != SASPA_F32) return 0;
+  return 1;
+}
+
+extern "C" int saspa_splitk_groupnorm(const SaspaGemmParams* gp, const SaspaGroupNormParams* np, void* stream) {
+  if (!gp || !np) return SASPA_EINVAL;
+  const SaspaGemmParams& g = *gp;
+  const SaspaGroupNormParams& p = *np;
+  if (!g.workspace || g.ksplit < 2 || !p.gamma || !p.beta || !p.y) return SASPA_EINVAL;
+  if (!saspa_splitk_groupnorm_eligible(gp, np)) return SASPA_ERANGE;
+  if (p.ldy % 4 || (g.rowvec && g.ldrv % 4) || !aligned16(g.workspace) || !aligned16(p.y) || (g.bias && !aligned16(g.bias)) ||
+      (g.rowvec && !aligned16(g.rowvec)) || !aligned16(p.gamma) || !aligned16(p.beta))
+    return SASPA_EALIGN;
+  if (g.rowvec && g.ldrv == 0 && p.batch > 1) {
+    // one row vector for every image: blockIdx.y * 0 -- fine
+  }
+  if (p.batch > 65535) return SASPA_ERANGE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(p.groups, p.batch);
+  if (g.dtype == SASPA_BF16) hipLaunchKernelGGL(splitk_gn_kernel<bf16_t>, grid, dim3(256), 0, s, g, p);
+  else hipLaunchKernelGGL(splitk_gn_kernel<float>, grid, dim3(256), 0, s, g, p);
   SASPA_CHECK_LAUNCH();
   return 0;
 }

@@ -342,8 +342,9 @@ class _Net:
         if pfx in self.temb_tables:
             rv = self.temb_cur_views[pfx] if step is None else self.temb_tables[pfx][step]
         h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
-        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv, gn_unit=self.gn_unit)
-        h = ops.groupnorm(h, p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU)
+        # conv1 -> norm2 -> SiLU: conv1's output has no other reader (fuse_gn: one launch for reduce + GroupNorm at the small levels)
+        h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv, gn_unit=self.gn_unit,
+                     fuse_gn=(p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU))
         if pfx + ".conv_shortcut.w" in p:
             sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"], x2=x2)
         else:

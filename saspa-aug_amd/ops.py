@@ -158,6 +158,11 @@ def _as_over_stats():
     return os.environ.get("SASPA_GEMM_AS_OVER_STATS", "1") != "0"
 
 
+def splitk_gn_enabled():
+    """SASPA_SPLITK_GN=0: conv1 -> norm2 of the small levels runs as conv (+ reduce) and GroupNorm launches again (A/B knob)."""
+    return os.environ.get("SASPA_SPLITK_GN", "1") != "0"
+
+
 def gn_onepass_enabled():
     """SASPA_GN_ONEPASS=0: small-image GroupNorms run as statistics pass + apply pass again (A/B knob)."""
     return os.environ.get("SASPA_GN_ONEPASS", "1") != "0"
@@ -188,12 +193,16 @@ def _gn_stats_for(p, out, gn_unit, b, hw, n):
 
 def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=None, rowvec=None,
          residual=None, alpha=1.0, act=ACT_NONE, out=None, n_out=None, variant=0, korder=None, ksplit=None, out_hw=None,
-         gn_unit=None):
+         gn_unit=None, fuse_gn=None):
     """Implicit-GEMM conv of channels-last ``x`` (optionally channel-concatenated with
     ``x2``) with packed weights ``w`` [N, kh*kw*(C0+C1)].  Returns [B, Ho, Wo, round8(N)]
     (pad channels zero).  ``korder``: K order the weights were packed in (default: the tensor's
     ``saspa_korder`` attribute set by the packer, else tap-major).  ``gn_unit``: the output feeds a GroupNorm whose
-    groups are multiples of this many channels -> the epilogue leaves its statistics (`_gn_stats_for`)."""
+    groups are multiples of this many channels -> the epilogue leaves its statistics (`_gn_stats_for`).
+    ``fuse_gn`` = (gamma, beta, groups, eps, act): the conv's ONLY consumer is this GroupNorm (ResnetBlock2D.conv1 -> norm2 ->
+    SiLU), so the call returns the NORMALISED tensor: where the conv runs on K slices and an image's group fits one workgroup
+    (the 8x8 / 16x16 levels) the reduce launch, the statistics and the apply pass are one launch (saspa_splitk_groupnorm, ABI
+    18: the un-normalised output is never written); otherwise the conv runs as usual and `groupnorm` follows."""
     _check_dev(x, w, bias, x2, rowvec, residual, out)
     lib = _lib.load()
     b, h, wd, c0 = x.shape
@@ -249,10 +258,31 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     if gn_unit and kh == 1 and kw == 1 and c1 == 0 and x.dtype == torch.bfloat16 and _as_over_stats() and \
             lib.saspa_gemm_as_eligible(C.byref(p)) == 2:
         gn_unit = None
+    meta = (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0, residual is not None, n // 2 if act == ACT_GEGLU else n)
+    if fuse_gn is not None:
+        gamma, beta, groups, eps, gact = fuse_gn
+        if splitk_gn_enabled() and residual is None and act == ACT_NONE and out.shape[-1] == n:
+            _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)          # the heuristic WITHOUT epilogue statistics: nobody reads them
+            q = _lib.GroupNormParams()
+            q.dtype = _dt(out)
+            q.x0, q.x1, q.c0, q.c1 = _ptr(out), None, n, 0
+            q.ldx0, q.ldx1 = _pitch4(out), 0
+            q.batch, q.hw, q.groups, q.eps = b, ho * wo, int(groups), float(eps)
+            q.gamma, q.beta = _ptr(gamma), _ptr(beta)
+            q.partial, q.nsplit, q.scale_shift = None, 0, None
+            q.act, q.y, q.ldy = int(gact), _ptr(out), _pitch4(out)
+            if p.ksplit > 1 and lib.saspa_splitk_groupnorm_eligible(C.byref(p), C.byref(q)):
+                p.defer_reduce = 1
+                _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv, deferred reduce)"), meta)
+                _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(q), _stream()), "saspa_splitk_groupnorm")
+                return out
+            p.ksplit, p.workspace, p.defer_reduce = 1, None, 0
+        h = conv(x, w, bias, kh=kh, kw=kw, stride=stride, pad=pad, upsample=upsample, x2=x2, rowvec=rowvec, residual=residual, alpha=alpha,
+                 act=act, out=out, n_out=n_out, variant=variant, korder=korder, ksplit=ksplit, out_hw=out_hw, gn_unit=gn_unit)
+        return groupnorm(h, gamma, beta, groups, eps, gact)
     _gs = _gn_stats_for(p, out, gn_unit, b, ho * wo, n)  # noqa: F841   (set BEFORE the split-K heuristic looks at p)
     _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
-    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"),
-            (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0, residual is not None, n // 2 if act == ACT_GEGLU else n))
+    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"), meta)
     return out
 
 

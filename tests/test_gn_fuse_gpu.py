@@ -161,3 +161,41 @@ def test_network_level_equivalence(dev, monkeypatch):
     assert nstats["0"] == 0 and nstats["1"] >= 12, nstats          # every GroupNorm of both networks but the first of each
     d = (outs["1"] - outs["0"]).abs().max().item()
     assert torch.isfinite(outs["1"]).all() and d < 3e-2 * outs["0"].abs().max().item(), d
+
+
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+@pytest.mark.parametrize("b,h,w_,cin,cout,ks,rv", [(16, 8, 8, 1280, 1280, None, True), (4, 16, 16, 1280, 1280, 2, True), (2, 16, 16, 640, 1280, 4, False),
+                                                  (3, 8, 8, 320, 640, 3, True)])
+def test_conv_fused_reduce_groupnorm(dev, dtype, b, h, w_, cin, cout, ks, rv, monkeypatch):
+    """ops.conv(..., fuse_gn=...) -> saspa_splitk_groupnorm (ABI 18): split-K reduce + bias + time-embedding row + GroupNorm +
+    SiLU of a small-level ResnetBlock2D.conv1 -> norm2 in one launch, against the same conv followed by the GroupNorm launches
+    (SASPA_SPLITK_GN=0) and against torch."""
+    g = torch.Generator().manual_seed(11 + cin + (ks or 0))
+    x = torch.randn(b, h, w_, cin, generator=g).to(dev, dtype)
+    wt32 = torch.randn(cout, 9 * cin, generator=g) / math.sqrt(9 * cin)
+    if dtype == BF:
+        wt = W.to_chunk_major(wt32, 9, BF).to(dev, BF)
+        wt.saspa_korder = 1
+    else:
+        wt = wt32.to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    rowvec = torch.randn(cout, generator=g).to(dev) if rv else None
+    gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev), (0.1 * torch.randn(cout, generator=g)).to(dev)
+    fg = (gamma, beta, 32, 1e-5, ops.ACT_SILU)
+    got = ops.conv(x, wt, bias, kh=3, kw=3, pad=1, rowvec=rowvec, ksplit=ks, fuse_gn=fg)
+    monkeypatch.setenv("SASPA_SPLITK_GN", "0")
+    two = ops.conv(x, wt, bias, kh=3, kw=3, pad=1, rowvec=rowvec, ksplit=ks, fuse_gn=fg)
+    scale = two.float().abs().max().item()
+    d = (got.float() - two.float()).abs().max().item()
+    assert d <= (1.6e-2 if dtype == BF else 2e-5) * scale, (d, scale)
+    # torch reference on the same (rounded) operands
+    xr = x.float().cpu().permute(0, 3, 1, 2)
+    wr = (wt32.to(dtype).float() if dtype == BF else wt32).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xr, wr, bias.cpu(), padding=1)
+    if rv:
+        ref = ref + rowvec.cpu()[None, :, None, None]
+    if dtype == BF:
+        ref = ref.to(BF).float()
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(ref, 32, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 3, 1)
+    e = (got.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert e < (3e-2 if dtype == BF else 1e-4), e

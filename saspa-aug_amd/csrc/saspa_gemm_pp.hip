@@ -49,27 +49,45 @@ __device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
 }
 
+// workgroup barrier that orders LDS accesses only (global stores stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int FN, bool PW, bool UP, bool ONEBAR>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, const int ntiles_abl, const int npart8) {
   // diagnostic ablation (tools/gemm_ablate.py, `make ABLATION=1` only): bits 28..31 of the tile count
-  //   1: no MFMA   2: no fragment reads   4: no DMA issue   8: no barriers
-  const int ntiles = ntiles_abl & 0x07ffffff;
+  //   1: no MFMA   2: no fragment reads   4: no DMA issue   8: no barriers;  bits 24..26 (SASPA_GEMM_EPI_ABLATE): epilogue
+  const int ntiles = ntiles_abl & 0x00ffffff;
 #ifdef SASPA_GEMM_ABLATION
   const int abl = (ntiles_abl >> 28) & 15;
   const bool stamp = (ntiles_abl >> 27) & 1;           // block 0 leaves (shader clocks, 100 MHz ticks) of its K loop in out[0..15]
-  unsigned long long st0 = 0, sr0 = 0, st1 = 0, sr1 = 0;
+  unsigned long long st0 = 0, sr0 = 0, st1 = 0, sr1 = 0, sr_setup = 0, sr_issue = 0, sr_e0 = 0, sr_e1 = 0;
   const unsigned long long sr_entry = __builtin_amdgcn_s_memrealtime();
+  const int eabl = (ntiles_abl >> 24) & 7;             // epilogue ablation: 1 = no global stores, 2 = no epilogue at all
 #else
-  constexpr int abl = 0;
+  constexpr int abl = 0, eabl = 0;
 #endif
   constexpr int BM = 256, BN = 64 * FN, BK = 64, SZ = 2;
   constexpr int STAGE = (BM + BN) * 8;                 // u32x4 per LDS buffer
   constexpr int CP = BN + 8;                           // epilogue row pitch (elements)
   constexpr int EPI = 128 * CP * SZ / 16;              // u32x4 for one 128-row half of the output tile
   constexpr int NLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-  __shared__ u32x4 lds[NLDS];
+  // bias [BN] and time-embedding rows [half][image of the half][BN] of the tile live behind the staging buffers, staged by
+  // LDS-DMA when the tile is set up (a half spans at most 4 images: saspa_gemm_pp_eligible wants H*W >= 43 with a row
+  // vector).  The epilogue reads them back from LDS -- one read per column fragment where the half lies in one image
+  // (loading them in the epilogue cost one dependent L2 round trip per fragment: 5 - 10 us of the ~20 us epilogue that
+  // tools/pp_clock.py measured in round 4).  They are part of the SAME __shared__ object as the staging buffers on purpose:
+  // with DMA into a second LDS object in the kernel the compiler put s_waitcnt vmcnt(0) in front of every fragment read of
+  // the K loop (+ 10 - 25 % per launch).
+  constexpr int NIMG = 4;
+  constexpr int ADDV_F = (1 + 2 * NIMG) * BN;          // floats
+  __shared__ u32x4 lds[NLDS + ADDV_F / 4];
+  float* const addvb = reinterpret_cast<float*>(lds + NLDS);
+  float* const addvr = addvb + BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -359,11 +377,39 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   };
 
   setup_tile(tile);
+#ifdef SASPA_GEMM_ABLATION
+  if (stamp) sr_setup = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (gridDim.y == 1) {
+      // bias and time-embedding rows of this tile -> LDS by DMA (no register, no wait: they are the oldest vector-memory
+      // operations of the tile, so the first counted vmcnt of the K loop covers them).  256-byte pieces, one wave each:
+      // piece row 0 = bias, row 1 + half * NIMG + il = row vector of image (first image of the half) + il.  A descriptor
+      // with zero records turns a piece into zeros (no bias / no row vector / image beyond the batch / column beyond N).
+      // (The previous tile's epilogue ended with a barrier after its last read of these slots.)
+      constexpr int PCS = BN / 64;
+      const int nimg = p.rowvec ? NIMG : 1;
+      for (int pc = wave; pc < PCS * (1 + 2 * NIMG); pc += 8) {
+        const int rowi = pc / PCS, part = pc - rowi * PCS;
+        const int voff = (bn * BN + part * 64 + lane) * 4;
+        if (rowi == 0) {
+          const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, p.bias ? p.N * 4 : 0, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(addvb + part * 64), 4, voff, 0, 0, 0);
+        } else {
+          const int hi = rowi - 1, h = hi / NIMG, il = hi - h * NIMG;
+          const int img = min(bm * BM + h * 128, p.M - 1) / hw + il;
+          const bool live = p.rowvec && il < nimg && (long long)img * hw < p.M;
+          const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowvec) + (live ? (long long)img * p.ldrv : 0), (short)0,
+                                                              live ? p.N * 4 : 0, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void_t*)(addvr + hi * BN + part * 64), 4, voff, 0, 0, 0);
+        }
+      }
+    }
 
     if (nk > 0) {
       if (ONEBAR) {
@@ -510,6 +556,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
       begin_stage();
 #pragma unroll
       for (int s = 0; s < 3; ++s) stage_slice(s, oth);
+#ifdef SASPA_GEMM_ABLATION
+      if (stamp) sr_issue = __builtin_amdgcn_s_memrealtime();
+#endif
       wait_vm<6>();
       __builtin_amdgcn_s_barrier();
       if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm = 1 group runs one barrier behind
@@ -548,143 +597,248 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     const bool has_next = next < ntiles;
 
     // ---- epilogue ----
+    // lane geometry re-derived from the thread id behind an optimisation barrier: the copies computed before the K loop would
+    // otherwise be kept alive across it -- the loop has no register to spare, so they were spilled and came back as ~50
+    // one-at-a-time scratch reloads (each followed by s_waitcnt vmcnt(0)) in front of the epilogue's LDS writes
+    int etid = threadIdx.x;
+    asm volatile("" : "+v"(etid));
+    const int elane = etid & 63;
+    const int ewave = __builtin_amdgcn_readfirstlane(etid >> 6);
+    const int ewm = ewave >> 2, ewn = ewave & 3, efrow = elane & 15, efg = elane >> 4;
     T* out = reinterpret_cast<T*>(p.out) + ooff;
     const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + ooff : nullptr;
-    if (gridDim.y > 1) {
+#ifdef SASPA_GEMM_ABLATION
+    if (stamp) sr_e0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (eabl == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if (gridDim.y > 1) {
       float* ws = p.workspace + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int m = cbm * BM + wm * 128 + i * 16 + frow;
+        const int m = cbm * BM + ewm * 128 + i * 16 + efrow;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          const int n = cbn * BN + wn * (16 * FN) + j * 16 + fg * 4;
+          const int n = cbn * BN + ewn * (16 * FN) + j * 16 + efg * 4;
           if (n >= p.N) continue;
           *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) =
               make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
       }
     } else {
+      // Two wave groups (ewm = 0 / 1), each finishing ITS 128-row half of the tile, 64 rows at a time:
+      //     stage 64 rows as bf16 in the group's LDS block | barrier | coalesced store pass by the group's 256 threads | barrier
+      // All 8 waves run the same program.  (Until round 4 the halves took turns -- `if (wm == h)` staged 128 rows, then all 8
+      // waves stored them -- with the other half's 160 accumulator registers waiting: the store pass had no registers for a
+      // batch of residual loads, its spill reloads waited on vmcnt(0) = on the stores just issued, and bias / row vector came
+      // from global memory once per fragment: tools/pp_clock.py measured 22 - 40 us for 160 KB per workgroup.)
+      // The barriers order LDS accesses only (lds_barrier: lgkmcnt(0) + s_barrier).  __syncthreads() also waits for vmcnt(0),
+      // i.e. for every global store of the pass to be acknowledged by L2: each pass then drained (4 - 6 us for the chip's
+      // 21 MB) before the next one could stage; now the stores drain under the following pass and the kernel's tail.
       T* ct = reinterpret_cast<T*>(lds);
+      T* ctg = ct + ewm * (64 * CP);                     // this group's staging block
+      const int gtid = etid & 255;
+      const int m0 = cbm * BM + ewm * 128;
+      const int img0 = min(m0, p.M - 1) / hw;
+      const int mnext = (img0 + 1) * hw;                 // first row of the next image
+      // bias + time-embedding row from addv: one LDS read per column fragment where the half lies in one image, one per
+      // accumulator fragment where it spans several (H*W < 128) -- wave-uniform, no global load either way
+      const bool multi = p.rowvec && m0 + 128 > mnext && mnext < p.M;
+      const float* avb = addvb + ewn * (16 * FN) + efg * 4;
+      const float* av = addvr + ewm * NIMG * BN + ewn * (16 * FN) + efg * 4;
+      float4 add[FN];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (wm == h) {
-          // bias + time-embedding row of the half-tile's FIRST image, loaded once per column fragment (5 loads
-          // in flight together instead of one dependent L2 round trip per accumulator fragment); rows that
-          // belong to a later image (only when H*W < 128) take the reload path
-          const int m0 = cbm * BM + h * 128;
-          const int img0 = min(m0, p.M - 1) / hw;
-          const int mnext = (img0 + 1) * hw;             // first row of the next image
-          float4 add[FN];
+      for (int j = 0; j < FN; ++j) {
+        add[j] = *reinterpret_cast<const float4*>(avb + j * 16);
+        const float4 r4 = *reinterpret_cast<const float4*>(av + j * 16);
+        add[j].x += r4.x; add[j].y += r4.y; add[j].z += r4.z; add[j].w += r4.w;   // bias + row vector, then acc + that
+      }
+      // GroupNorm statistics (SaspaGemmParams.gn_stats: one (sum, sum of squares) per 128-row block and unit): thread
+      // (unit gu, row group grg) of the group keeps its partial sums over both passes
+      const int gunit = p.gn_stats ? p.gn_unit : BN;
+      const int nunits = BN / gunit;
+      const int rgs = 256 / nunits;
+      const int gu = gtid % nunits, grg = gtid / nunits;
+      float gsm = 0.f, gsq = 0.f;
+      constexpr int CPR = BN / 8;
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            const int n = cbn * BN + wn * (16 * FN) + j * 16 + fg * 4;
-            add[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N) {
-              if (p.bias) add[j] = *reinterpret_cast<const float4*>(p.bias + n);
-              if (p.rowvec) {
-                const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (long long)img0 * p.ldrv + n);
-                add[j].x += r4.x; add[j].y += r4.y; add[j].z += r4.z; add[j].w += r4.w;
-              }
-            }
-          }
+      for (int qt = 0; qt < 2; ++qt) {
+        if (!multi) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int mrow = i * 16 + frow;
-            const int m = m0 + mrow;
-            const bool other = p.rowvec && m >= mnext && m < p.M;
-            const float* rvd = other ? p.rowvec + (long long)(m / hw) * p.ldrv : nullptr;   // rare: row of a later image
+          for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              const int ncol = wn * (16 * FN) + j * 16 + fg * 4;
-              const int n = cbn * BN + ncol;
-              float v[4] = {acc[i][j][0] + add[j].x, acc[i][j][1] + add[j].y, acc[i][j][2] + add[j].z, acc[i][j][3] + add[j].w};
-              if (other && n < p.N) {
-                const float4 a4 = *reinterpret_cast<const float4*>(rvd + n);
-                const float4 c4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                // same association as the common path: acc + (bias + rowvec)
-                v[0] = acc[i][j][0] + (c4.x + a4.x); v[1] = acc[i][j][1] + (c4.y + a4.y);
-                v[2] = acc[i][j][2] + (c4.z + a4.z); v[3] = acc[i][j][3] + (c4.w + a4.w);
-              }
+              const f32x4& c = acc[qt * 4 + i][j];
+              float v[4] = {c[0] + add[j].x, c[1] + add[j].y, c[2] + add[j].z, c[3] + add[j].w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-              Elem<T>::store4(ct + mrow * CP + ncol, v);
+              Elem<T>::store4(ctg + (i * 16 + efrow) * CP + ewn * (16 * FN) + j * 16 + efg * 4, v);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (qt * 4 + i) * 16 + efrow;
+            const int il = (m >= mnext ? 1 : 0) + (m >= mnext + hw ? 1 : 0) + (m >= mnext + 2 * hw ? 1 : 0);   // image of this row
+            const float* avr = av + il * BN;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              float4 ad = *reinterpret_cast<const float4*>(avb + j * 16);
+              const float4 r4 = *reinterpret_cast<const float4*>(avr + j * 16);
+              ad.x += r4.x; ad.y += r4.y; ad.z += r4.z; ad.w += r4.w;
+              const f32x4& c = acc[qt * 4 + i][j];
+              float v[4] = {c[0] + ad.x, c[1] + ad.y, c[2] + ad.z, c[3] + ad.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+              Elem<T>::store4(ctg + (i * 16 + efrow) * CP + ewn * (16 * FN) + j * 16 + efg * 4, v);
             }
           }
         }
-        __syncthreads();
+        lds_barrier();
+        const int mq = m0 + qt * 64;                     // first output row of the staged block
         if (p.act == SASPA_ACT_GEGLU) {
           // weights are packed per 160 columns (weights.pack_geglu): [80 values | their 80 gates]; a 320-wide tile holds
           // two such groups -> 160 output features per tile row
           if constexpr (FN == 5) {
-            constexpr int CPR = 20;
-            for (int q = tid; q < 128 * CPR; q += 512) {
-              const int row = q / CPR, ch = q - row * CPR;
-              const int m = cbm * BM + h * 128 + row;
+            constexpr int CPG = 20;
+            for (int q = gtid; q < 64 * CPG; q += 256) {
+              const int row = q / CPG, ch = q - row * CPG;
+              const int m = mq + row;
               if (m >= p.M) continue;
               const int sub = ch / 10, c10 = ch - sub * 10;
               float a[8], g[8];
-              unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + sub * 160 + c10 * 8), a);
-              unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + sub * 160 + 80 + c10 * 8), g);
+              unpack8(*reinterpret_cast<const uint4*>(ctg + row * CP + sub * 160 + c10 * 8), a);
+              unpack8(*reinterpret_cast<const uint4*>(ctg + row * CP + sub * 160 + 80 + c10 * 8), g);
 #pragma unroll
               for (int e = 0; e < 8; ++e) a[e] = fast_gelu_mul(a[e], g[e]);
               *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + cbn * 160 + ch * 8) = pack8(a);
             }
           }
-          __syncthreads();
-          continue;
-        }
-        constexpr int CPR = BN / 8;
-        for (int q = tid; q < 128 * CPR; q += 512) {
-          const int row = q / CPR, ch = q - row * CPR;
-          const int m = cbm * BM + h * 128 + row, n = cbn * BN + ch * 8;
-          if (m >= p.M || n >= p.N) continue;
-          u32x4 c4 = *reinterpret_cast<const u32x4*>(ct + row * CP + ch * 8);
-          if (res || p.act != SASPA_ACT_NONE) {
-            float a[8];
-            unpack8(__builtin_bit_cast(uint4, c4), a);
-            if (p.act == SASPA_ACT_SILU) {
+        } else {
+          // one 16-byte chunk: activation / residual on the staged bf16 values, then the coalesced store
+          auto finish = [&](u32x4 c4, const uint4 r4, const int row, const int ch, const int m, const int n) __attribute__((always_inline)) {
+            if (res || p.act != SASPA_ACT_NONE) {
+              float a[8];
+              unpack8(__builtin_bit_cast(uint4, c4), a);
+              if (p.act == SASPA_ACT_SILU) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
-            } else if (p.act == SASPA_ACT_RELU) {
+                for (int e = 0; e < 8; ++e) a[e] = a[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[e]));
+              } else if (p.act == SASPA_ACT_RELU) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
+                for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
+              }
+              if (res) {
+                float b[8];
+                unpack8(r4, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+              }
+              if (p.act == SASPA_ACT_ADD_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
+              }
+              c4 = __builtin_bit_cast(u32x4, pack8(a));
+              if (p.gn_stats) *reinterpret_cast<u32x4*>(ctg + row * CP + ch * 8) = c4;   // the statistics read the STORED values
             }
-            if (res) {
-              float b[8];
-              Elem<bf16_t>::load_chunk(res + (long long)m * p.ldr + n, b);
+            if (eabl != 1) *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
+          };
+          constexpr int NIT = 64 * CPR / 256;            // chunks per thread and pass: 10 (BN = 320) / 8 (BN = 256)
+          static_assert(NIT * 256 == 64 * CPR && NIT % 2 == 0, "store pass: whole rounds of 256 chunks");
+          if (mq + 64 <= p.M && cbn * BN + BN <= p.N) {
+            // whole block inside the output (wave-uniform): two batches of NIT / 2 chunks, every residual load of a batch in
+            // flight before the first is used (the rolled loop below waits for one L2 round trip per chunk)
+            constexpr int NB = NIT / 2;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) a[e] += b[e];
-            }
-            if (p.act == SASPA_ACT_ADD_RELU) {
+            for (int b0 = 0; b0 < NIT; b0 += NB) {
+              uint4 r4[NB];
+              int row[NB], ch[NB];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.0f);
+              for (int k = 0; k < NB; ++k) {
+                const int q = gtid + (b0 + k) * 256;
+                row[k] = q / CPR;
+                ch[k] = q - row[k] * CPR;
+                r4[k] = make_uint4(0u, 0u, 0u, 0u);
+              }
+              if (res) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                  r4[k] = *reinterpret_cast<const uint4*>(res + (long long)(mq + row[k]) * p.ldr + cbn * BN + ch[k] * 8);
+              }
+#pragma unroll
+              for (int k = 0; k < NB; ++k) {
+                const u32x4 c4 = *reinterpret_cast<const u32x4*>(ctg + row[k] * CP + ch[k] * 8);
+                finish(c4, r4[k], row[k], ch[k], mq + row[k], cbn * BN + ch[k] * 8);
+              }
             }
-            c4 = __builtin_bit_cast(u32x4, pack8(a));
-            if (p.gn_stats) *reinterpret_cast<u32x4*>(ct + row * CP + ch * 8) = c4;   // the statistics read the STORED values
+          } else {
+            for (int q = gtid; q < 64 * CPR; q += 256) {
+              const int row = q / CPR, ch = q - row * CPR;
+              const int m = mq + row, n = cbn * BN + ch * 8;
+              if (m >= p.M || n >= p.N) continue;
+              const u32x4 c4 = *reinterpret_cast<const u32x4*>(ctg + row * CP + ch * 8);
+              uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
+              if (res) r4 = *reinterpret_cast<const uint4*>(res + (long long)m * p.ldr + n);
+              finish(c4, r4, row, ch, m, n);
+            }
           }
-          *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = c4;
         }
+#ifdef SASPA_GEMM_ABLATION
+        if (stamp && qt == 0) sr_e1 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (p.gn_stats) {
-          // GroupNorm statistics of this half tile = one 128-row block (SaspaGemmParams.gn_stats)
-          __syncthreads();
-          const int nrows = min(128, p.M - (cbm * BM + h * 128));
-          if (nrows > 0)
-            gn_tile_stats<512>(ct, CP, nrows, BN / p.gn_unit, p.gn_unit, reinterpret_cast<float*>(ct + 128 * CP),
-                               p.gn_stats + ((long long)(cbm * 2 + h) * (p.N / p.gn_unit) + (cbn * BN) / p.gn_unit) * 2);
+          lds_barrier();                               // values a residual / activation changed were written back above
+          const int nrows = min(64, p.M - mq);
+          if (grg < rgs) {
+            for (int r = grg; r < nrows; r += rgs) {
+              const uint32_t* src = reinterpret_cast<const uint32_t*>(ctg + r * CP + gu * gunit);
+              for (int j = 0; j < gunit; j += 2) {
+                // two bf16 per dword: v_dot2c_f32_bf16 against (1, 1) and against itself (as gn_tile_stats)
+                const bf16x2_t w2 = __builtin_bit_cast(bf16x2_t, src[j >> 1]);
+                gsm = __builtin_amdgcn_fdot2_f32_bf16(w2, __builtin_bit_cast(bf16x2_t, 0x3F803F80u), gsm, false);
+                gsq = __builtin_amdgcn_fdot2_f32_bf16(w2, w2, gsq, false);
+              }
+            }
+          }
         }
-        __syncthreads();
+        lds_barrier();
+      }
+      if (p.gn_stats) {
+        // fixed summation order (rows of a row group in order, then the row groups in order): deterministic
+        float* scr = reinterpret_cast<float*>(ct + 128 * CP) + ewm * 512;
+        if (grg < rgs) {
+          scr[(grg * nunits + gu) * 2] = gsm;
+          scr[(grg * nunits + gu) * 2 + 1] = gsq;
+        }
+        lds_barrier();
+        if (gtid < nunits * 2 && m0 < p.M) {
+          const int uu = gtid >> 1, k = gtid & 1;
+          float a = 0.f;
+          for (int g = 0; g < rgs; ++g) a += scr[(g * nunits + uu) * 2 + k];
+          p.gn_stats[((long long)(cbm * 2 + ewm) * (p.N / p.gn_unit) + (cbn * BN) / p.gn_unit + uu) * 2 + k] = a;
+        }
+        lds_barrier();
       }
     }
 #ifdef SASPA_GEMM_ABLATION
-    if (stamp && tid == 0) {
-      // diagnostics: the caller's `out` allocation extends 4 x 8 bytes per workgroup beyond M rows
+    if (stamp && etid == 0) {
+      // diagnostics: the caller's `out` allocation extends 16 x 8 bytes per workgroup beyond M rows
+      const unsigned long long sr_issued = __builtin_amdgcn_s_memrealtime();
       __threadfence();
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<T*>(p.out) + (long long)p.M * p.ldo) + 4 * blockIdx.x;
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<T*>(p.out) + (long long)p.M * p.ldo) + 16 * blockIdx.x;
       o[0] = sr0;
       o[1] = sr1;
       o[2] = ((st1 - st0) << 20) | ((sr0 - sr_entry) & 0xfffff);   // loop clocks | entry -> loop start ticks
-      o[3] = __builtin_amdgcn_s_memrealtime();
+      o[3] = __builtin_amdgcn_s_memrealtime();                     // this wave's stores are visible
+      o[4] = sr_entry;
+      o[5] = sr_setup;                                             // per-lane im2col state ready
+      o[6] = sr_issue;                                             // prologue DMAs issued
+      o[7] = sr_e0;                                                // K loop drained, epilogue starts
+      o[8] = sr_e1;                                                // half 0: stores issued
+      o[9] = sr_issued;                                            // half 1: stores issued
     }
 #endif
     if (!has_next) break;
@@ -704,7 +858,8 @@ int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
   static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;   // diagnostics only
   static const int stamp = getenv("SASPA_GEMM_STAMP") ? (atoi(getenv("SASPA_GEMM_STAMP")) & 1) : 0;
-  const int ta = tiles | (abl << 28) | (stamp << 27);
+  static const int eabl = getenv("SASPA_GEMM_EPI_ABLATE") ? (atoi(getenv("SASPA_GEMM_EPI_ABLATE")) & 7) : 0;
+  const int ta = tiles | (abl << 28) | (stamp << 27) | (eabl << 24);
   const int npart8 = saspa_gemm_npart8(p, BM, BN, gx, tiles);
   if (pw) hipLaunchKernelGGL((gemm_pp_kernel<FN, true, false, ONEBAR>), grid, dim3(512), 0, s, p, ta, npart8);
   else if (p.upsample) hipLaunchKernelGGL((gemm_pp_kernel<FN, false, true, ONEBAR>), grid, dim3(512), 0, s, p, ta, npart8);
@@ -731,6 +886,8 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
     if ((p.hout - 1) * p.stride > hv - 1 || (p.wout - 1) * p.stride > wv - 1) return false;
     if (p.upsample && (p.hin >= 16000 || p.win >= 16000)) return false;
   }
+  // the epilogue stages the row vector of at most 4 images per 128-row half tile
+  if (p.rowvec && p.hout * p.wout < 43) return false;
   // per-lane offsets are 24-bit pixel index x 24-bit pitch products
   if ((long long)p.batch * p.hin * p.win >= (1ll << 24) || p.M >= (1 << 24)) return false;
   if ((long long)p.lda0 * 2 >= (1ll << 24) || (long long)p.lda1 * 2 >= (1ll << 24)) return false;

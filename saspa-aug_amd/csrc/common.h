@@ -158,6 +158,13 @@ __device__ __forceinline__ u32x4 buf_load(rsrc_t r, unsigned voff, unsigned soff
 }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for vmcnt(0): in an epilogue that means for every
+// global store issued so far to be acknowledged by L2 -- the stores of one pass then drain before the next pass may stage.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // GroupNorm statistics of one block of <= 128 finished output rows held in LDS as bf16 (`ct`: rows of `cp` elements, the
 // STORED values): per unit of `unit` consecutive channels (nunits of them, nunits divides NT) the sum and the sum of squares
 // over rows [0, nrows) -> dst[nunits][2].  Fixed summation order (thread (unit, row group) over its interleaved rows, then
@@ -182,7 +189,7 @@ __device__ __forceinline__ void gn_tile_stats(const bf16_t* ct, const int cp, co
     scratch[(rg * nunits + u) * 2] = sm;
     scratch[(rg * nunits + u) * 2 + 1] = sq;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < nunits * 2) {
     const int uu = tid >> 1, k = tid & 1;
     float a = 0.f;

@@ -49,12 +49,6 @@ __device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
 }
 
-// workgroup barrier that orders LDS accesses only (global stores stay in flight)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int FN, bool PW, bool UP, bool ONEBAR>

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   constexpr int EPI = 128 * CP * SZ / 16;              // u32x4 for one 128-row half of the output tile
   constexpr int NLDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
   // bias [BN] and time-embedding rows [half][image of the half][BN] of the tile live behind the staging buffers, staged by
-  // LDS-DMA when the tile is set up (a half spans at most 4 images: saspa_gemm_pp_eligible wants H*W >= 43 with a row
-  // vector).  The epilogue reads them back from LDS -- one read per column fragment where the half lies in one image
+  // LDS-DMA when the tile is set up (a half spans at most 4 images when H*W >= 43; smaller images take a per-fragment
+  // global-load path).  The epilogue reads them back from LDS -- one read per column fragment where the half lies in one image
   // (loading them in the epilogue cost one dependent L2 round trip per fragment: 5 - 10 us of the ~20 us epilogue that
   // tools/pp_clock.py measured in round 4).  They are part of the SAME __shared__ object as the staging buffers on purpose:
   // with DMA into a second LDS object in the kernel the compiler put s_waitcnt vmcnt(0) in front of every fragment read of
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
               Elem<T>::store4(ctg + (i * 16 + efrow) * CP + ewn * (16 * FN) + j * 16 + efg * 4, v);
             }
           }
-        } else {
+        } else if (hw >= 43) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = m0 + (qt * 4 + i) * 16 + efrow;
@@ -684,6 +684,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
               float4 ad = *reinterpret_cast<const float4*>(avb + j * 16);
               const float4 r4 = *reinterpret_cast<const float4*>(avr + j * 16);
               ad.x += r4.x; ad.y += r4.y; ad.z += r4.z; ad.w += r4.w;
+              const f32x4& c = acc[qt * 4 + i][j];
+              float v[4] = {c[0] + ad.x, c[1] + ad.y, c[2] + ad.z, c[3] + ad.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+              Elem<T>::store4(ctg + (i * 16 + efrow) * CP + ewn * (16 * FN) + j * 16 + efg * 4, v);
+            }
+          }
+        } else {
+          // images of fewer than 43 pixels: a half spans more than the NIMG staged rows -- the row vector comes from global
+          // memory per accumulator fragment (tiny problems only; the dispatcher never sends a production shape here)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (qt * 4 + i) * 16 + efrow;
+            const float* rvd = p.rowvec + (long long)(min(m, p.M - 1) / hw) * p.ldrv;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const int n = cbn * BN + ewn * (16 * FN) + j * 16 + efg * 4;
+              float4 ad = *reinterpret_cast<const float4*>(avb + j * 16);
+              if (n < p.N) {
+                const float4 r4 = *reinterpret_cast<const float4*>(rvd + n);
+                ad.x += r4.x; ad.y += r4.y; ad.z += r4.z; ad.w += r4.w;
+              }
               const f32x4& c = acc[qt * 4 + i][j];
               float v[4] = {c[0] + ad.x, c[1] + ad.y, c[2] + ad.z, c[3] + ad.w};
 #pragma unroll
@@ -880,8 +902,6 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
     if ((p.hout - 1) * p.stride > hv - 1 || (p.wout - 1) * p.stride > wv - 1) return false;
     if (p.upsample && (p.hin >= 16000 || p.win >= 16000)) return false;
   }
-  // the epilogue stages the row vector of at most 4 images per 128-row half tile
-  if (p.rowvec && p.hout * p.wout < 43) return false;
   // per-lane offsets are 24-bit pixel index x 24-bit pitch products
   if ((long long)p.batch * p.hin * p.win >= (1ll << 24) || p.M >= (1 << 24)) return false;
   if ((long long)p.lda0 * 2 >= (1ll << 24) || (long long)p.lda1 * 2 >= (1ll << 24)) return false;

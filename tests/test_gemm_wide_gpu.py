@@ -67,6 +67,47 @@ def test_wide_conv_concat_rowvec_residual_silu(dev, h):
     assert_close(from_nhwc(out, cout), ref, BF, what="wide concat conv, shared row, SiLU")
 
 
+@pytest.mark.parametrize("b,h,w_", [(9, 8, 8), (7, 8, 11), (11, 7, 7), (5, 6, 7)])
+def test_wide_conv_rowvec_images_smaller_than_a_half_tile(dev, b, h, w_):
+    """Time-embedding rows where a 128-row half of the tile spans several images: 43 <= H*W < 128 reads the rows of up to four
+    images from the LDS slots the tile set-up staged (8x8, 8x11: the deepest UNet level at 512x512 / 512x704; 7x7: four images
+    per half), H*W < 43 takes the per-fragment global-load path.  Un-split (ksplit = 1), ragged M, residual + alpha."""
+    cin, cout = 64, 320
+    x = q(_rand(b, cin, h, w_, seed=31), BF)
+    wt = q(_rand(cout, cin, 3, 3, seed=32, scale=1 / math.sqrt(9 * cin)), BF)
+    bias, rv = _rand(cout, seed=33), _rand(b, cout, seed=34)
+    res = q(_rand(b, cout, h, w_, seed=35), BF)
+    ref = (F.conv2d(x, wt, bias, padding=1) + rv[:, :, None, None]) * 0.5 + res
+    out = ops.conv(to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF), bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev),
+                   residual=to_nhwc(res, BF, dev), alpha=0.5, variant=ops.GEMM_WIDE, ksplit=1)
+    assert_close(from_nhwc(out, cout), ref, BF, what=f"wide conv, rows of several images per half tile ({b}x{h}x{w_})")
+
+
+@pytest.mark.parametrize("b,h,w_,res_on", [(2, 16, 16, True), (3, 16, 24, False), (1, 32, 32, True)])
+def test_wide_conv_epilogue_groupnorm_statistics(dev, b, h, w_, res_on):
+    """GroupNorm statistics out of the wide kernel's epilogue (per 128-row block and unit of 10 channels: sum / sum of squares of
+    the STORED bf16 values, accumulated over the two 64-row passes of a wave group), with and without a residual."""
+    cin, cout, unit = 64, 320, 10
+    x = q(_rand(b, cin, h, w_, seed=41), BF)
+    wt = q(_rand(cout, cin, 3, 3, seed=42, scale=1 / math.sqrt(9 * cin)), BF)
+    bias, rv = _rand(cout, seed=43), _rand(b, cout, seed=44)
+    res = q(_rand(b, cout, h, w_, seed=45), BF) if res_on else None
+    out = ops.conv(to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF), bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev),
+                   residual=None if res is None else to_nhwc(res, BF, dev), variant=ops.GEMM_WIDE, ksplit=1, gn_unit=unit)
+    ref = F.conv2d(x, wt, bias, padding=1) + rv[:, :, None, None]
+    assert_close(from_nhwc(out, cout), ref if res is None else ref + res, BF, what="wide conv with statistics epilogue")
+    stats, u = out.saspa_gn[:2]
+    assert u == unit
+    m = b * h * w_
+    stored = out.reshape(m, -1)[:, :cout].float().cpu()
+    st = stats.float().cpu()
+    assert st.shape == (m // 128, cout // unit, 2)
+    for blk in range(m // 128):
+        rows = stored[blk * 128:(blk + 1) * 128].reshape(-1, cout // unit, unit)
+        torch.testing.assert_close(st[blk, :, 0], rows.sum((0, 2)), rtol=1e-3, atol=2e-2)
+        torch.testing.assert_close(st[blk, :, 1], (rows * rows).sum((0, 2)), rtol=1e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("m,k,n", [(300, 320, 960), (77, 768, 320), (1, 320, 1280), (4096, 1280, 320), (513, 64, 8)])
 def test_wide_linear(dev, m, k, n):
     x, wt, bias = q(_rand(m, k, seed=1), BF), q(_rand(n, k, seed=2, scale=1 / math.sqrt(k)), BF), _rand(n, seed=3)

@@ -28,8 +28,10 @@
 //     before the phase that first reads it.  Nothing is drained to vmcnt(0) inside the loop.
 //   * tail: tiles beyond the K range are "staged" with out-of-range offsets (the DMA writes zeros
 //     into slots nobody reads again), which keeps the per-wave vmcnt arithmetic uniform.
-//   * epilogue: two 128-row halves through LDS (bias / time-embedding row / alpha, then
-//     SiLU / residual on the coalesced 16-byte store pass); split-K writes fp32 slabs.
+//   * epilogue (round 4): each wave group finishes its own 128-row half, 64 rows at a time -- bias / time-embedding rows
+//     from LDS slots filled by DMA at tile set-up, bf16 staging, LDS-only barrier, coalesced 16-byte store pass with the
+//     residual loads of a batch in flight together, GroupNorm statistics accumulated over both passes; split-K writes
+//     fp32 slabs.  (profiles/r4_conv_epilogue.txt: what the previous form cost and why.)
 #include <cstdlib>
 
 #include "common.h"

@@ -68,6 +68,7 @@ class _PngWriters:
         n = int(os.environ.get("SASPA_PNG_PROCS", workers))
         self.procs, self.queues, self.feeders, self.next = [], [], [], 0
         self.threads, self.pending = None, []
+        self.submitted, self.max_depth = 0, 0        # images handed over / deepest backlog seen at a submit (diagnostics)
         if n <= 0:
             self.threads = ThreadPoolExecutor(max_workers=workers)
             return
@@ -103,6 +104,8 @@ class _PngWriters:
             raise ValueError("newline in an output path")
         self.queues[self.next].put((f"{h} {w} {c} {path}\n".encode("utf-8"), arr.tobytes()))
         self.next = (self.next + 1) % len(self.queues)
+        self.submitted += 1
+        self.max_depth = max(self.max_depth, sum(q.qsize() for q in self.queues))
 
     def close(self):
         if self.threads is not None:
@@ -154,6 +157,7 @@ class Settings:
     WEIGHTS_DIR: str = None            # local diffusers-format checkpoints; None -> synthetic weights
     PROMPTS_FILE: str = None
     DATASET_KWARGS: dict = field(default_factory=dict)
+    MAX_BATCHES: int = 0               # > 0: stop this rank after that many batches (rehearsals / diagnostics; the rest stays status 0)
 
 
 @dataclass
@@ -411,6 +415,27 @@ def default_prompts_file(s: Settings):
     return str(here / "gpt_prompts" / f"{name}-100-gpt_v1.txt")
 
 
+def _png_orientation(path):
+    """EXIF orientation of a PNG without decoding it: the eXIf chunk may sit before or after the IDAT chunks, so the chunk
+    headers are walked (8 bytes each, data skipped by seek) up to IEND.  1 when there is none."""
+    import struct
+    with open(path, "rb") as f:
+        if f.read(8) != b"\x89PNG\r\n\x1a\n":
+            return 1
+        while True:
+            head = f.read(8)
+            if len(head) < 8:
+                return 1
+            n, kind = struct.unpack(">I4s", head)
+            if kind == b"eXIf":
+                ex = Image.Exif()
+                ex.load(f.read(n))
+                return ex.get(0x0112, 1)
+            if kind == b"IEND":
+                return 1
+            f.seek(n + 4, 1)
+
+
 def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None,
               same_class_fn=None, ds_utils=None, captions=None, class_to_prompts=None):
     """Returns the work items in the reference's loop order.  Must be called right after
@@ -421,7 +446,10 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
             # 5-8 swap the sides, and the plan's bucket / noise shape must be the loaded image's
             with Image.open(path) as im:
                 w, h = im.size
-                if im.getexif().get(0x0112, 1) in (5, 6, 7, 8):
+                # PNG: Pillow's getexif() DECODES the picture to reach an eXIf chunk behind the pixel data (20 ms per
+                # 1024 x 683 source: 69 s of a 3 334-image plan, tools/config3_rehearsal.py); walk the chunk headers instead
+                orientation = _png_orientation(path) if im.format == "PNG" else im.getexif().get(0x0112, 1)
+                if orientation in (5, 6, 7, 8):
                     w, h = h, w
             th, tw, _ = utils.resize_target_size(h, w, s.RESOLUTION)
             return th, tw
@@ -731,6 +759,8 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
 
     import time as _time
     prof = os.environ.get("SASPA_PROFILE_LOOP") == "1"          # per-batch host timings in the log (diagnostics)
+    if s.MAX_BATCHES > 0:
+        batches = batches[:s.MAX_BATCHES]
     for bi, batch in enumerate(batches):
         try:
             t0 = _time.time()
@@ -798,4 +828,5 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
             filter_models=filter_models, weights_dir=s.WEIGHTS_DIR, device=fdev)
     if dist is not None:
         dist.barrier()
-    return dict(items=items, status=status, json_path=json_path, output_folder=output_folder)
+    return dict(items=items, status=status, json_path=json_path, output_folder=output_folder, mine=mine, n_batches=len(batches),
+                png_submitted=png.submitted, png_max_queue=png.max_depth)

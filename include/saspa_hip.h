@@ -61,6 +61,7 @@ extern "C" {
 
 #define SASPA_KORDER_TAP 0
 #define SASPA_KORDER_CHUNK 1
+#define SASPA_KORDER_CHUNK32 2   /* saspa_conv3x3_halo only (ABI 19): K = ((chunk32 * 9 + ky*3+kx) * 32 + c_in_chunk), chunks of 32 channels */
 
 /* ---- implicit-GEMM convolution / linear ----------------------------------
  * out[m][n] = act( alpha * (sum_k A[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n]) ) + residual[m][n]
@@ -246,6 +247,30 @@ int saspa_groupnorm_onepass(const SaspaGroupNormParams* p, void* stream);
  * hw * N / groups <= 12 288. */
 int saspa_splitk_groupnorm_eligible(const SaspaGemmParams* g, const SaspaGroupNormParams* n);
 int saspa_splitk_groupnorm(const SaspaGemmParams* g, const SaspaGroupNormParams* n, void* stream);
+
+/* ---- halo-tiled 3x3 conv with the CONSUMING GroupNorm (+SiLU) applied to its input tile in LDS (ABI 19) -----------------
+ * out = conv3x3(act(GroupNorm(cat(a0, a1)))) (+ bias + rowvec, * alpha, + residual, epilogue statistics: as saspa_gemm) in ONE
+ * launch: ResnetBlock2D's  norm1 -> SiLU -> conv1  and  norm2 -> SiLU -> conv2  (diffusers ResnetBlock2D.forward; SURVEY 8a
+ * a7.5 / a7.6).  Replaces saspa_groupnorm_apply + saspa_gemm for these layers: the normalised tensor is never written.
+ * p: the conv exactly as for saspa_gemm (bf16, 3x3 / stride 1 / pad 1, no upsampling, c0 / c1 multiples of 32 with c0 + c1 a
+ * multiple of 64, N % 320 == 0 or N % 256 == 0, hout * wout % 256 == 0, weights packed SASPA_KORDER_CHUNK32; ksplit /
+ * workspace / defer_reduce / gn_stats as for saspa_gemm).  g: the GroupNorm over the conv's INPUT channels, NULL for a plain
+ * conv of an already normalised tensor; its statistics come from the producers' epilogues (stats0 / stats1 / unit, see
+ * SaspaGroupNormParams) or from saspa_groupnorm_stats (partial / nsplit).  Same arithmetic and rounding points as the two
+ * launches it replaces (scale / shift in fp32, SiLU by v_exp + v_rcp, rounding to bf16 before the product).
+ * _eligible: non-zero if the launch can run; _ksplit: the K slices a requested factor really uses (slices are whole pairs of
+ * 32-channel chunks) -- size the workspace and set p->ksplit from it. */
+typedef struct SaspaConvGnParams {
+  const float* gamma_beta32;   /* [(c0 + c1) / 32][64]: per 32-channel chunk gamma[32] | beta[32] */
+  int groups;
+  float eps;
+  int act;                     /* SASPA_ACT_NONE | SASPA_ACT_SILU, applied after the affine */
+  const float* stats0; const float* stats1; int unit;
+  const float* partial; int nsplit;
+} SaspaConvGnParams;
+int saspa_conv3x3_halo_eligible(const SaspaGemmParams* p, const SaspaConvGnParams* g);
+int saspa_conv3x3_halo_ksplit(const SaspaGemmParams* p, int want);
+int saspa_conv3x3_halo(const SaspaGemmParams* p, const SaspaConvGnParams* g, void* stream);
 
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, CLIP LNs). */
 int saspa_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, long long rows, int C,

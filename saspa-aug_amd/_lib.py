@@ -58,6 +58,13 @@ class GroupNormParams(C.Structure):
     ]
 
 
+class ConvGnParams(C.Structure):
+    _fields_ = [
+        ("gamma_beta32", C.c_void_p), ("groups", C.c_int), ("eps", C.c_float), ("act", C.c_int),
+        ("stats0", C.c_void_p), ("stats1", C.c_void_p), ("unit", C.c_int), ("partial", C.c_void_p), ("nsplit", C.c_int),
+    ]
+
+
 class GemmF8Params(C.Structure):
     _fields_ = [
         ("a", C.c_void_p), ("lda", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -119,6 +126,9 @@ SYMBOLS = {
     "saspa_groupnorm_onepass": (_I, [C.POINTER(GroupNormParams), _P]),
     "saspa_splitk_groupnorm_eligible": (_I, [C.POINTER(GemmParams), C.POINTER(GroupNormParams)]),
     "saspa_splitk_groupnorm": (_I, [C.POINTER(GemmParams), C.POINTER(GroupNormParams), _P]),
+    "saspa_conv3x3_halo_eligible": (_I, [C.POINTER(GemmParams), C.POINTER(ConvGnParams)]),
+    "saspa_conv3x3_halo_ksplit": (_I, [C.POINTER(GemmParams), _I]),
+    "saspa_conv3x3_halo": (_I, [C.POINTER(GemmParams), C.POINTER(ConvGnParams), _P]),
     "saspa_abi_version": (_I, []),
     "saspa_build_arch": (C.c_char_p, []),
 }

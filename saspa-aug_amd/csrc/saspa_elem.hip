@@ -571,5 +571,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 18; }
+extern "C" int saspa_abi_version(void) { return 19; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

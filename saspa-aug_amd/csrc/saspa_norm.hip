@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -612,6 +613,8 @@ extern "C" int saspa_splitk_groupnorm(const SaspaGemmParams* gp, const SaspaGrou
   SASPA_CHECK_LAUNCH();
   return 0;
 }
+
+int saspa_gn_slabs(int c8) { return gn_geometry(c8).slabs; }
 
 extern "C" int saspa_groupnorm_stats(const SaspaGroupNormParams* pp, void* stream) {
   if (!pp) return SASPA_EINVAL;

@@ -286,6 +286,151 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     return out
 
 
+def halo_conv_enabled():
+    """SASPA_HALO=0: the resnet convs run as GroupNorm apply + im2col conv again (A/B knob for saspa_conv3x3_halo)."""
+    return os.environ.get("SASPA_HALO", "1") != "0"
+
+
+def _gn_source_stats(x, x2, groups):
+    """Epilogue statistics of the producers of x (| x2), as `groupnorm` would use them: (stats0, stats1, unit) or None."""
+    def _fresh(t):
+        g = getattr(t, "saspa_gn", None) if t is not None else None
+        if g is None or g[2] != t.data_ptr() or g[3] != t._version or g[0].shape[0] * 128 != t.shape[0] * t.shape[1] * t.shape[2]:
+            return None
+        return g
+    b, h, w, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    g0, g1 = _fresh(x), _fresh(x2)
+    ok = (g0 is not None and (x2 is None or g1 is not None) and gn_fusion_enabled() and (h * w) % 128 == 0
+          and (x2 is None or g1[1] == g0[1]) and c0 % g0[1] == 0 and c1 % g0[1] == 0 and ((c0 + c1) // groups) % g0[1] == 0
+          and g0[0].shape[1] * g0[1] == c0 and (x2 is None or g1[0].shape[1] * g1[1] == c1))
+    return (g0[0], g1[0] if g1 is not None else None, g0[1]) if ok else None
+
+
+def conv_gn(x, gn, w32, bias=None, *, x2=None, rowvec=None, residual=None, alpha=1.0, out=None, ksplit=None, gn_unit=None,
+            defer_to=None):
+    """out = conv3x3(act(GroupNorm(cat(x, x2)))) in ONE launch (saspa_conv3x3_halo, ABI 19): the GroupNorm (+ SiLU) is applied
+    to the conv's input tile in LDS -- ResnetBlock2D's norm -> SiLU -> conv.  gn = (gamma_beta32, groups, eps, act) or None
+    (plain halo conv of an already normalised x); w32: weights packed SASPA_KORDER_CHUNK32 (weights.to_chunk32_major).
+    Returns None when the launch is not eligible (the caller falls back to groupnorm + conv).  Statistics of x come from its
+    producer's epilogue when it left them (`saspa_gn`), else from a statistics pass launched here.  defer_to = (gamma, beta,
+    groups, eps, act): the conv's only consumer is that GroupNorm and the conv runs on K slices -> saspa_splitk_groupnorm sums the
+    slabs and normalises (as ops.conv(fuse_gn=...))."""
+    _check_dev(x, w32, bias, x2, rowvec, residual, out)
+    if x.dtype != torch.bfloat16 or not halo_conv_enabled():
+        return None
+    lib = _lib.load()
+    b, h, wd, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    n = w32.shape[0]
+    if x2 is not None and (tuple(x2.shape[:3]) != (b, h, wd) or x2.dtype != x.dtype):
+        raise ValueError(f"concat source {tuple(x2.shape)} does not match {tuple(x.shape)} (batch / height / width / dtype)")
+    if w32.shape[1] < 9 * (c0 + c1) or w32.dtype != x.dtype:
+        raise ValueError(f"weights {tuple(w32.shape)} {w32.dtype} do not fit a 3x3 window over {c0}+{c1} channels of {x.dtype}")
+    for name, t in (("residual", residual), ("out", out)):
+        if t is not None and (t.dim() != 4 or tuple(t.shape[:3]) != (b, h, wd) or t.shape[3] < n or t.dtype != x.dtype):
+            raise ValueError(f"{name} {tuple(t.shape)} {t.dtype} does not match the output [{b},{h},{wd},>={n}] {x.dtype}")
+    if bias is not None and bias.numel() < n:
+        raise ValueError("bias shorter than N")
+    if rowvec is not None and (rowvec.shape[-1] < n or (rowvec.dim() == 2 and rowvec.shape[0] not in (1, b))):
+        raise ValueError(f"rowvec {tuple(rowvec.shape)} must be [N] or [batch, N]")
+    p = _lib.GemmParams()
+    p.dtype = _lib.SASPA_BF16
+    p.a0, p.a1, p.c0, p.c1 = _ptr(x), _ptr(x2), c0, c1
+    p.lda0 = _pitch4(x)
+    p.lda1 = 0 if x2 is None else _pitch4(x2)
+    p.batch, p.hin, p.win, p.hout, p.wout = b, h, wd, h, wd
+    p.kh, p.kw, p.stride, p.pad, p.upsample = 3, 3, 1, 1, 0
+    p.w, p.ldw = _ptr(w32), w32.stride(0)
+    p.M, p.N, p.K = b * h * wd, n, 9 * (c0 + c1)
+    p.bias, p.rowvec = _ptr(bias), _ptr(rowvec)
+    p.ldrv = 0 if (rowvec is None or rowvec.dim() == 1 or rowvec.shape[0] == 1) else rowvec.stride(0)
+    p.residual = _ptr(residual)
+    p.ldr = 0 if residual is None else _pitch4(residual)
+    p.alpha, p.act = float(alpha), ACT_NONE
+    p.nb1 = p.nb2 = 1
+    p.korder = 2
+    q = None
+    keep = []
+    if gn is not None:
+        gb32, groups, eps, gact = gn
+        q = _lib.ConvGnParams()
+        q.gamma_beta32, q.groups, q.eps, q.act = _ptr(gb32), int(groups), float(eps), int(gact)
+        st = _gn_source_stats(x, x2, groups)
+        if st is not None:
+            q.stats0, q.stats1, q.unit = _ptr(st[0]), _ptr(st[1]), int(st[2])
+            keep.append(st)
+    # eligibility is decided BEFORE any allocation / statistics launch (out / ldo of a would-be output: dense rows of round8(N))
+    p.out, p.ldo = _ptr(x), round8(n) if out is None else _pitch4(out)
+    if q is not None and not q.stats0:
+        q.partial, q.nsplit = _ptr(x), 1            # placeholders for the eligibility check
+    if not lib.saspa_conv3x3_halo_eligible(C.byref(p), C.byref(q) if q is not None else None):
+        return None
+    if q is not None and not q.stats0:
+        # no epilogue statistics on the input: the statistics pass of `groupnorm`, then the fused apply + conv
+        ctot = c0 + c1
+        nsplit = _gn_nsplit(b, h * wd, ctot // 8)
+        partial = torch.empty((b * nsplit * ctot * 2,), device=x.device, dtype=torch.float32)
+        g = _lib.GroupNormParams()
+        g.dtype = _dt(x)
+        g.x0, g.x1, g.c0, g.c1 = _ptr(x), _ptr(x2), c0, c1
+        g.ldx0, g.ldx1 = _pitch4(x), (0 if x2 is None else _pitch4(x2))
+        g.batch, g.hw, g.groups, g.eps = b, h * wd, int(groups), float(eps)
+        g.gamma, g.beta = _ptr(gb32), _ptr(gb32)       # not read by the statistics pass
+        g.partial, g.nsplit, g.scale_shift = _ptr(partial), nsplit, None
+        g.act, g.y, g.ldy = 0, None, 0
+        _lib.check(lib.saspa_groupnorm_stats(C.byref(g), _stream()), "saspa_groupnorm_stats")
+        q.partial, q.nsplit = _ptr(partial), nsplit
+        keep.append(partial)
+    if out is None:
+        nc = round8(n)
+        out = (torch.zeros if nc != n else torch.empty)((b, h, wd, nc), device=x.device, dtype=x.dtype)
+    p.out, p.ldo = _ptr(out), _pitch4(out)
+    meta = (p.M, p.N, p.K, 3, 1, 0, c1 > 0, residual is not None, n)
+    flops = 2.0 * p.M * p.N * p.K
+
+    def _split(force):
+        p.ksplit, p.workspace = 1, None
+        p.sharing = 1 if _TWIN[0] else 0
+        p.korder = 1                                  # the heuristic knows the im2col kernels' orders only; same K
+        ks = lib.saspa_gemm_suggest_ksplit(C.byref(p)) if force is None else int(force)
+        p.korder = 2
+        ks = lib.saspa_conv3x3_halo_ksplit(C.byref(p), ks)
+        if ks > 1:
+            ws = torch.empty((ks * p.M * p.N,), device=x.device, dtype=torch.float32)
+            p.ksplit, p.workspace = ks, C.c_void_p(ws.data_ptr())
+            return ws
+        return None
+
+    qq = C.byref(q) if q is not None else None
+    if defer_to is not None:
+        gamma, beta, groups2, eps2, gact2 = defer_to
+        if splitk_gn_enabled() and residual is None and out.shape[-1] == n:
+            _ws = _split(ksplit)
+            g2 = _lib.GroupNormParams()
+            g2.dtype = _dt(out)
+            g2.x0, g2.x1, g2.c0, g2.c1 = _ptr(out), None, n, 0
+            g2.ldx0, g2.ldx1 = _pitch4(out), 0
+            g2.batch, g2.hw, g2.groups, g2.eps = b, h * wd, int(groups2), float(eps2)
+            g2.gamma, g2.beta = _ptr(gamma), _ptr(beta)
+            g2.partial, g2.nsplit, g2.scale_shift = None, 0, None
+            g2.act, g2.y, g2.ldy = int(gact2), _ptr(out), _pitch4(out)
+            if p.ksplit > 1 and lib.saspa_splitk_groupnorm_eligible(C.byref(p), C.byref(g2)):
+                p.defer_reduce = 1
+                _launch("gemm", flops, lambda: _lib.check(lib.saspa_conv3x3_halo(C.byref(p), qq, _stream()), "saspa_conv3x3_halo(deferred reduce)"), meta)
+                _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(g2), _stream()), "saspa_splitk_groupnorm")
+                return out
+            p.ksplit, p.workspace, p.defer_reduce = 1, None, 0
+        _gs = _gn_stats_for(p, out, gn_unit, b, h * wd, n)  # noqa: F841
+        _ws = _split(ksplit)  # noqa: F841
+        _launch("gemm", flops, lambda: _lib.check(lib.saspa_conv3x3_halo(C.byref(p), qq, _stream()), "saspa_conv3x3_halo"), meta)
+        return groupnorm(out, gamma, beta, groups2, eps2, gact2)
+    _gs = _gn_stats_for(p, out, gn_unit, b, h * wd, n)  # noqa: F841
+    _ws = _split(ksplit)  # noqa: F841
+    _launch("gemm", flops, lambda: _lib.check(lib.saspa_conv3x3_halo(C.byref(p), qq, _stream()), "saspa_conv3x3_halo"), meta)
+    return out
+
+
 def _linear_params(x2, w, bias, r2, o2, alpha, act, rowvec, variant, m, n, k):
     p = _lib.GemmParams()
     p.dtype = _gemm_dt(x2)

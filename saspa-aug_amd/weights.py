@@ -652,6 +652,23 @@ def to_chunk_major(packed, taps, dtype):
     return packed.view(n, taps, c // bk, bk).permute(0, 2, 1, 3).reshape(n, k).contiguous()
 
 
+def to_chunk32_major(packed, taps=9):
+    """[N, taps*C] tap-major -> K = ((chunk32 * taps + tap) * 32 + c_in_chunk): the packing of saspa_conv3x3_halo
+    (SASPA_KORDER_CHUNK32: one (chunk32, tap) slot is one half of a 64-deep K-tile)."""
+    n, k = packed.shape
+    c = k // taps
+    assert c * taps == k and c % 32 == 0
+    return packed.view(n, taps, c // 32, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+
+
+def pack_gamma_beta32(gamma, beta):
+    """GroupNorm affine -> [C / 32][64] fp32: per 32-channel chunk gamma[32] | beta[32] (SaspaConvGnParams.gamma_beta32: one
+    256-byte LDS-DMA piece per chunk)."""
+    c = gamma.numel()
+    assert c % 32 == 0 and beta.numel() == c
+    return torch.cat([gamma.float().reshape(-1, 32), beta.float().reshape(-1, 32)], 1).contiguous()
+
+
 def pack_linear(w, k_pad=None):
     n, k = w.shape
     kp = round8(k) if k_pad is None else k_pad

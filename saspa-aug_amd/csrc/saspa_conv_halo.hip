@@ -47,14 +47,32 @@ struct HaloGeom {
   int ntiles;
 };
 
-__device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+// MFMA through inline asm with the accumulator pinned in the ACCUMULATOR file ("+a").  With the builtin the compiler keeps the
+// accumulators in the same file as everything else, re-homes them between MFMAs and, at 256 registers, spills accumulator
+// fragments to scratch inside the K loop -- every reload sits behind s_waitcnt vmcnt(0), i.e. drains the weight ring (measured:
+// 0.9 us per reload group; 115 -> 154 us per launch when a schedule edit added nine of them).  hipcc gives a 2-waves-per-SIMD
+// kernel that uses AGPRs 128 AGPRs + 128 VGPRs, so the first FOUR 16-column fragments of a wave's row block live in AGPRs
+// (8 x 4 x 4 = 128) and the fifth (FN = 5) stays with the builtin in VGPRs (32) beside the operand fragments (36).
+// Hazards the compiler does not pad for an asm statement (guide 5.7 item 2): a VALU-written operand -> MFMA needs two wait
+// states (`first` opens the phase's block with s_nop 1: the operands are ds_read results, but a compiler copy may sit in
+// front); an accumulator is read again as C no sooner than 19 MFMAs later; its first VALU reader is the epilogue.
+__device__ __forceinline__ void mma_a(const u32x4& wf, const u32x4& xf, f32x4& acc, const bool first) {
+  const f32x4 a = __builtin_bit_cast(f32x4, wf), b = __builtin_bit_cast(f32x4, xf);
+  if (first) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mma_v(const u32x4& wf, const u32x4& xf, f32x4& acc) {
+  // (asm too: with AGPRs in the kernel the builtin is selected in its AGPR form and copied in and out of the full file)
+  const f32x4 a = __builtin_bit_cast(f32x4, wf), b = __builtin_bit_cast(f32x4, xf);
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int FN, bool GN>
+// REG: W % 16 == 0 -- a 16-pixel fragment never straddles image rows, so the row wraps between a wave's fragments are
+// wave-uniform (scalar arithmetic) instead of a per-lane nibble table
+template <int FN, bool GN, bool REG>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p, const SaspaConvGnParams g, const HaloGeom geo) {
   constexpr int BM = 256, BN = 64 * FN, SZ = 2;
   constexpr int HROWS = 480;
@@ -127,6 +145,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
   // 4 bits per fragment in xw) -- two registers instead of eight (the K loop has none to spare)
   int X0 = 0;
   unsigned xw = 0;
+  int ad[4] = {0, 0, 0, 0};                            // LDS byte addresses of the NEXT phase's four pixel fragments
+  unsigned hoffn = kInvalid;                           // DMA offset of the next phase's halo piece (if it has one)
+  unsigned hvalid = 0;                                 // bit j: this lane's row of halo piece j is a pixel of the image (not padding)
   unsigned offb0 = 0;
   int nrows = 0;
   int stg = 0;                                         // K-tiles of weights staged so far
@@ -156,6 +177,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
         const int iy = prow - 1, ix = pcol - 1;
         const bool ok = r < Lh && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
         const unsigned rel = (unsigned)(iy * Wd + ix);
+        if (j == 0) hvalid = 0;
+        hvalid |= (ok && (wave + 8 * j) * 16 < HROWS) ? (1u << j) : 0u;
         hoffb[(j * 2 + 0) * 512 + tid] = ok ? rel * (unsigned)(p.lda0 * SZ) + (unsigned)(hlc * 16) : kInvalid;
         hoffb[(j * 2 + 1) * 512 + tid] = ok ? rel * (unsigned)(p.lda1 * SZ) + (unsigned)(hlc * 16) : kInvalid;
       }
@@ -166,12 +189,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
       X0 = ((oy + 1) * wp + ox + 1 - qf) * 64 + fg * 16;
       xw = 0;
       int wr = 0;
+      if (REG) ox = (rem0 + wm * 128) % Wd;            // the fragment's first pixel: the same row arithmetic for every lane -> scalar
 #pragma unroll
       for (int i = 1; i < 8; ++i) {
         ox += 16;
         while (ox >= Wd) { ox -= Wd; ++wr; }
         xw |= (unsigned)wr << (4 * i);                 // <= 15 row wraps inside 128 pixels: W >= 9 (checked by _eligible)
       }
+      if (REG) xw = (unsigned)__builtin_amdgcn_readfirstlane((int)xw);
     }
     offb0 = (unsigned)((bn * BN + wave * 8 + lr) * p.ldw * SZ + kcs * 16);
     nrows = p.N - bn * BN;
@@ -193,14 +218,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
                                              soffw + i * 64 * p.ldw * SZ, 0, 0);
   };
   // halo piece j of 32-channel chunk c32 (global index over [source 0 | source 1]) -> halo buffer hb
-  auto stage_h = [&](const int j, const int c32, const int hb) __attribute__((always_inline)) {
+  auto stage_h = [&](const int j, const int c32, const int hb, const bool direct = false) __attribute__((always_inline)) {
     const int cc = c32 * 32;
     const bool live = cc < ctot;
     const bool s0 = cc < p.c0;
     const int ld = s0 ? p.lda0 : p.lda1;
     const T* base = (s0 ? a0 + (long long)img * hw * p.lda0 + cc : a1 + (long long)img * hw * p.lda1 + (cc - p.c0));
     const rsrc_t rs = make_desc(base, live);
-    const unsigned off = hoffb[(j * 2 + (s0 ? 0 : 1)) * 512 + wave * 64 + lane_now()];
+    if ((wave + 8 * j) * 16 >= HROWS) return;          // pieces 30, 31 lie beyond the buffer (the strict vmcnt count does not depend on them)
+    // the offset was fetched from the LDS table between the previous phase's MFMAs (the prologue reads it here)
+    const unsigned off = direct ? hoffb[(j * 2 + (s0 ? 0 : 1)) * 512 + wave * 64 + lane_now()] : hoffn;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + hb + (wave + 8 * j) * 64), 16, (int)off, 0, 0, 0);
   };
   // gamma | beta of chunk c32 (host-packed [C / 32][64] floats) -> gb[sb]: one 256-byte piece, issued by EVERY wave (same
@@ -225,34 +252,103 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
     }
   };
   const bool gsilu = GN && g.act == SASPA_ACT_SILU;
-  auto transform = [&](const int j, const int hb, const int sb) __attribute__((always_inline)) {
+  // LDS accesses of the normalisation through inline asm: written as plain loads, the compiler puts s_waitcnt vmcnt(0) in front
+  // of the scale / shift reads (it cannot tell them from the gamma | beta DMA target next to them), which drains the weight
+  // ring eight times per period.  The explicit lgkmcnt + sched_barrier pair is rule 18 of the guide (an asm ds_read's consumer
+  // must not be hoisted above the wait).
+  // (the asm result is a FLOAT vector on purpose: with an integer 4-vector as "=v" output hipcc 7.2 reads element 0 for elements
+  // 0 and 1 -- checked in isolation --, with f32x4 the sub-registers are right)
+  auto lds_rd = [](const unsigned byte_addr) __attribute__((always_inline)) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+  };
+  constexpr unsigned SSB_BYTES = (unsigned)(NLDS * 16 + ADDV_F * 4 + 128 * 4 + 128 * 4);      // byte offset of ss[] inside lds
+  // half a piece per phase: 4 of the 8 channels of this lane's 16 bytes of halo piece hs >> 1 (~150 cycles of VALU, which fits
+  // beside the other wave group's 20 MFMAs; a whole piece per phase did not).  Split in two so that its LDS reads are the FIRST
+  // instructions of a phase's read section and their latency runs under the fragment reads and the DMA issue:
+  //   tr_issue : ds_read of the 8 data bytes, 4 scales, 4 shifts            (top of the read section)
+  //   tr_finish: lgkmcnt(0), affine + SiLU, ds_write                       (after the DMA issue; the write is retired by the
+  //              lgkmcnt(0) every phase executes ahead of its MFMAs -- two barriers before any other wave reads the row)
+  unsigned long long trd = 0;
+  f32x4 trs = {0.f, 0.f, 0.f, 0.f}, trt = {0.f, 0.f, 0.f, 0.f};
+  unsigned trda = 0;
+  auto tr_issue = [&](const int hs, const int hb, const int sb) __attribute__((always_inline)) {
+    const int j = hs >> 1, h = hs & 1;
     const int ln = lane_now();
-    const unsigned off = hoffb[(j * 2) * 512 + wave * 64 + ln];
     const int hlc = (ln & 3) ^ (((ln >> 4) & 1) << 1);
-    if (off != kInvalid) {                             // padding stays zero: the conv pads the NORMALISED tensor
-      u32x4* ptr = lds + hb + (wave + 8 * j) * 64 + ln;
-      const u32x4 d = *ptr;
-      const float* sc = ssb + sb * 64 + hlc * 8;
-      const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
-      const float4 t0 = *reinterpret_cast<const float4*>(sc + 32), t1 = *reinterpret_cast<const float4*>(sc + 36);
-      const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-      float v[8];
-      unpack8(__builtin_bit_cast(uint4, d), v);
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)lds;
+    trda = lds_base + (unsigned)((hb + (wave + 8 * j) * 64 + ln) * 16 + h * 8);
+    const unsigned sa = lds_base + SSB_BYTES + (unsigned)(sb * 256 + hlc * 32 + h * 16);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(trd) : "v"(trda));      // (a 64-bit SCALAR: 2-vectors as asm outputs have the sub-register bug too)
+    trs = lds_rd(sa);
+    trt = lds_rd(sa + 128);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tr_finish = [&](const int hs) __attribute__((always_inline)) {
+    const int j = hs >> 1;
+    if ((hvalid >> j) & 1u) {                          // padding stays zero: the conv pads the NORMALISED tensor
+      const unsigned d0 = (unsigned)trd, d1 = (unsigned)(trd >> 32);
+      float v[4] = {__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
+                    __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
+      if (gsilu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float y = v[e] * sv[e] + tv[e];
-        if (gsilu) y = silu_fast(y);
-        v[e] = y;
+        for (int e = 0; e < 4; ++e) v[e] = silu_fast(v[e] * trs[e] + trt[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * trs[e] + trt[e];
       }
-      *ptr = __builtin_bit_cast(u32x4, pack8(v));
+      const unsigned long long o = (unsigned long long)pack2(v[0], v[1]) | ((unsigned long long)pack2(v[2], v[3]) << 32);
+      asm volatile("ds_write_b64 %0, %1" ::"v"(trda), "v"(o) : "memory");
     }
   };
 
   int cur = OFF_B0, oth = OFF_B0 + BB;
 
-  f32x4 acc[8][FN];
+  f32x4 acc[8][4];                                     // AGPRs (asm MFMA)
+  f32x4 accv[8];                                       // fifth column fragment (FN = 5): VGPRs (builtin MFMA)
   u32x4 wb[FN], xa[4];
+
+  // LDS addresses of the four pixel fragments phase (TT, P) multiplies: window origin + tap offset, chunk ^= 2 on rows with bit 2
+  // set.  Computed one phase AHEAD, between the MFMAs of the previous phase (the read section of a phase is what the other
+  // wave group's matrix block has to cover: address arithmetic in front of the ds_reads made it 30 % longer)
+  auto addr4 = [&](auto tc, auto pc) __attribute__((always_inline)) {
+    constexpr int TT = decltype(tc)::value, P = decltype(pc)::value;
+    constexpr int KK = P >> 1, I0 = 4 * (P & 1);
+    constexpr int S = 2 * TT + KK;                     // slot of the period
+    constexpr int hb = S < 9 ? OFF_H0 : OFF_H1;
+    constexpr int tap = S < 9 ? S : S - 9;
+    constexpr int dy = tap / 3, dx = tap - dy * 3;
+    int toff = dy * wp64 + dx * 64;
+    // opaque to LICM: the 8 x 9 (fragment, tap) addresses are loop invariants the compiler would otherwise precompute, keep in
+    // 72 registers and spill (230 scratch reloads inside the loop, each behind vmcnt(0))
+    asm volatile("" : "+s"(toff));
+    int x0v = X0;
+    if constexpr (REG) {
+      int xws = (int)xw;
+      asm volatile("" : "+v"(x0v), "+s"(xws));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0v + ((((xws >> (4 * (I0 + i))) & 15) << 7) + toff + (I0 + i) * 1024);
+        ad[i] = (x ^ ((x >> 3) & 32)) + hb * 16;
+      }
+    } else {
+      unsigned xwv = xw;
+      asm volatile("" : "+v"(xwv), "+v"(x0v));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0v + (int)(((xwv >> (4 * (I0 + i))) & 15u) << 7) + (toff + (I0 + i) * 1024);
+        ad[i] = (x ^ ((x >> 3) & 32)) + hb * 16;
+      }
+    }
+  };
+  // halo piece schedule (piece index or -1): chunk 2 pr + 1 -> buffer 1 at (0,1) (0,2) (1,0) (1,1) -- its last reader was phase
+  // (8,3) --; chunk 2 pr + 2 -> buffer 0 at (4,3) (5,0) (5,1) (5,2) -- last reader (4,1).  Both have landed at the phase-3 wait
+  // of K-tiles 1 / 5, where the chunk's scale / shift are derived; the eight half-piece normalisation steps follow, one per phase.
+  auto halo_piece = [](const int tt, const int p) constexpr {
+    return (tt == 0 && (p == 1 || p == 2)) ? p - 1 : (tt == 1 && p <= 1) ? 2 + p : (tt == 4 && p == 3) ? 0 : (tt == 5 && p <= 2) ? 1 + p : -1;
+  };
+  auto halo_is_b = [](const int tt) constexpr { return tt <= 1; };
 
   // one phase of K-tile TT (0..8 inside the period starting at chunk pair `pr`) out of weight buffer `cur`.  Phase P multiplies
   // the kk = P >> 1 half of the K-tile (ONE (chunk32, tap) slot) against four of the wave's eight pixel fragments: the weight
@@ -260,6 +356,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
   auto phase = [&](auto tc, auto pc, const int pr) __attribute__((always_inline)) {
     constexpr int TT = decltype(tc)::value, P = decltype(pc)::value;
     constexpr int KK = P >> 1, I0 = 4 * (P & 1);
+    constexpr int TN = P == 3 ? (TT + 1) % 9 : TT, PN = (P + 1) & 3;          // the following phase
+    // ---- read section (the other wave group owns the matrix pipe) ----
+    // normalisation steps: step q of a chunk is ISSUED (its LDS reads) in phase q of the window and FINISHED (VALU + write) in
+    // phase q + 1, so nothing in a read section waits for it.  Windows: chunk B K-tiles 2, 3 (+ (4,0)), chunk A' K-tiles 6, 7 (+ (8,0))
+    constexpr int PH = TT * 4 + P;
+    constexpr int qB = PH - 8, qA = PH - 24;          // phase index inside the window
+    constexpr bool issB = GN && qB >= 0 && qB < 8, finB = GN && qB >= 1 && qB <= 8;
+    constexpr bool issA = GN && qA >= 0 && qA < 8, finA = GN && qA >= 1 && qA <= 8;
     if constexpr ((P & 1) == 0) {
       const int ln = lane_now();
       const int rb = cur + (wn * (16 * FN) + (ln & 15)) * 8 + (((ln >> 4) ^ (ln & 7)) ^ (KK ? 4 : 0));
@@ -267,68 +371,64 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
       for (int j = 0; j < FN; ++j) wb[j] = lds[rb + j * 16 * 8];
       __builtin_amdgcn_sched_barrier(0);               // weight reads are issued (and counted) before the halo reads
     }
-    {
-      constexpr int S = 2 * TT + KK;                   // slot of the period
-      constexpr int hb = S < 9 ? OFF_H0 : OFF_H1;
-      constexpr int tap = S < 9 ? S : S - 9;
-      constexpr int dy = tap / 3, dx = tap - dy * 3;
-      int toff = dy * wp64 + dx * 64;
-      // opaque to LICM: the 8 x 9 (fragment, tap) addresses are loop invariants the compiler would otherwise precompute, keep in
-      // 72 registers and spill (230 scratch reloads inside the loop, each behind vmcnt(0)); 3 VALU per read instead
-      asm volatile("" : "+s"(toff));
-      unsigned xwv = xw;
-      int x0v = X0;
-      asm volatile("" : "+v"(xwv), "+v"(x0v));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = x0v + (int)(((xwv >> (4 * (I0 + i))) & 15u) << 7) + (toff + (I0 + i) * 1024);
-        const int a = (x ^ ((x >> 3) & 32)) + hb * 16;               // chunk ^= 2 on rows with bit 2 set
-        xa[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(lds) + a);
-      }
-    }
-    // weight pieces of K-tile t+2 follow the LAST fragment read of buffer `cur` (phase 2): pieces 0, 1 in phase 3, pieces 2.. in
-    // phase 0 of the next K-tile (where the buffer is `oth`)
+    for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(lds) + ad[i]);
+    // weight pieces of K-tile t+2 follow the LAST fragment read of buffer `cur` (phase 2): pieces 0, 1 in phase 3, one piece in
+    // each of phases 0.. of the next K-tile (where the buffer is `oth`)
+    const int c32b = 2 * (pr0 + pr) + 1;
+    // (past the slice this is the next slice's first chunk, or zero records past the last channel: loaded, normalised, never read)
+    const int c32a = 2 * (pr0 + pr) + 2;
+    constexpr int lj = halo_piece(TT, P);
+    if constexpr (lj >= 0 && P != 3) stage_h(lj, halo_is_b(TT) ? c32b : c32a, halo_is_b(TT) ? OFF_H1 : OFF_H0);
+    if constexpr (GN && TT == 0 && P == 1) stage_gb(c32b, 1);
+    if constexpr (GN && TT == 5 && P == 0) stage_gb(c32a, 0);
     if constexpr (P == 3) {
       begin_stage();
       stage_b(0, cur);
       stage_b(1, cur);
-    }
-    if constexpr (P == 0) {
+      stage_b(2, cur);
+      // (4,3): the first piece of chunk A' goes out BEHIND the weight pieces and stays in flight across this phase's wait
+      if constexpr (lj >= 0) stage_h(lj, c32a, OFF_H0);
+    } else if constexpr (P == 0) {
 #pragma unroll
-      for (int i = 2; i < FN; ++i) stage_b(i, oth);
+      for (int i = 3; i < FN; ++i) stage_b(i, oth);    // >= 3 phases in flight before the phase-3 wait
     }
-    // halo reload of the chunk that is NOT being read: two pieces in each of phases 1, 2 of two consecutive K-tiles
-    constexpr bool loadB = (TT == 0 || TT == 1) && (P == 1 || P == 2);           // chunk 2 pr + 1 -> buffer 1
-    constexpr bool loadA = (TT == 5 || TT == 6) && (P == 1 || P == 2);           // chunk 2 pr + 2 -> buffer 0
-    constexpr int lj = ((TT == 1 || TT == 6) ? 2 : 0) + (P == 2 ? 1 : 0);
-    const int c32b = 2 * (pr0 + pr) + 1;
-    const int c32a = (pr + 1 < npr) ? 2 * (pr0 + pr) + 2 : 0x3fffff;              // past the slice: zero records
-    if constexpr (loadB) stage_h(lj, c32b, OFF_H1);
-    if constexpr (loadA) stage_h(lj, c32a, OFF_H0);
-    if constexpr (GN) {
-      if constexpr (TT == 0 && P == 1) stage_gb(c32b, 1);
-      if constexpr (TT == 5 && P == 1) stage_gb(c32a, 0);
-      if constexpr (TT == 2 && P == 0) make_ss(c32b, 1);
-      if constexpr (TT == 7 && P == 0) { if (pr + 1 < npr) make_ss(c32a, 0); }
-      constexpr bool trB = (TT == 2 && P >= 1) || (TT == 3 && P == 0);
-      constexpr bool trA = (TT == 7 && P >= 1) || (TT == 8 && P == 0);
-      constexpr int tj = (trA || trB) ? ((TT == 2 || TT == 7) ? P - 1 : 3) : 0;
-      if constexpr (trB) transform(tj, OFF_H1, 1);
-      if constexpr (trA) { if (pr + 1 < npr) transform(tj, OFF_H0, 0); }
-    }
-    // phase 3: everything but the two weight pieces just issued has landed -- K-tile t+1 (read from the next phase on) and, in
-    // K-tiles 1 / 6, the halo pieces and gamma | beta issued in phases 1, 2 of this and the previous K-tile
-    if constexpr (P == 3) wait_vm<2>();
-    constexpr bool wrote = GN && ((TT == 2) || (TT == 3 && P == 0) || (TT == 7) || (TT == 8 && P == 0));
-    if constexpr (wrote) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // scale / shift or normalised rows are in LDS before the barrier
-    else if constexpr (P == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");   // weight fragment reads retired: the slot may be restaged
+    if constexpr (finB) tr_finish(qB - 1);
+    if constexpr (finA) tr_finish(qA - 1);
+    if constexpr (issB) tr_issue(qB, OFF_H1, 1);
+    if constexpr (issA) tr_issue(qA, OFF_H0, 0);       // (past the slice: the next slice's chunk or zeros; nobody reads it)
+    // phase 3: everything but the three weight pieces just issued has landed -- K-tile t+1 (read from the next phase on) and, in
+    // K-tiles 1 / 6, the halo pieces and gamma | beta of the chunk being reloaded
+    if constexpr (P == 3) wait_vm<(lj >= 0 ? 4 : 3)>();
+    if constexpr (GN && P == 3 && TT == 1) make_ss(c32b, 1);                      // gamma | beta of the chunk have just landed
+    if constexpr (GN && P == 3 && TT == 5) make_ss(c32a, 0);
+    constexpr bool wrote = GN && P == 3 && (TT == 1 || TT == 5);
+    if constexpr (wrote) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // scale / shift or normalised rows are in LDS before the barrier
+    else if constexpr (P == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); // weight fragment reads retired: the slot may be restaged
     __builtin_amdgcn_s_barrier();
+    // ---- matrix section; between the MFMAs: the next phase's addresses, the next halo piece's offset, and (GN) this phase's
+    // share of the normalisation of the chunk that landed ----
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) mma(wb[j], xa[i], acc[I0 + i][j]);
+      for (int j = 0; j < 4; ++j) mma_a(wb[j], xa[i], acc[I0 + i][j], i == 0 && j == 0);
+      if constexpr (FN == 5) mma_v(wb[4], xa[i], accv[I0 + i]);
+    }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (GN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // incl. the normalisation reads issued in this phase (consumed in the next)
+    // everything below issues while the 20 MFMAs drain (the matrix pipe runs 16 cycles per instruction, its issue takes 8): no
+    // register of the fragments is live any more, so the normalisation's temporaries cost the loop nothing
+    __builtin_amdgcn_sched_barrier(0);
+    addr4(ic<TN>{}, ic<PN>{});
+    constexpr int nj = halo_piece(TN, PN);
+    if constexpr (nj >= 0) {
+      if ((wave + 8 * nj) * 16 < HROWS) {
+        // source 0 or 1 of the chunk the next piece belongs to (wave-uniform)
+        const int cn = (halo_is_b(TN) ? c32b : c32a) * 32;
+        hoffn = hoffb[(nj * 2 + (cn < p.c0 ? 0 : 1)) * 512 + wave * 64 + lane_now()];
+      }
+    }
     __builtin_amdgcn_s_barrier();
   };
   auto ktile = [&](auto tc, const int pr) __attribute__((always_inline)) {
@@ -342,9 +442,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
   setup_tile(tile);
   for (;;) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     if (gridDim.y == 1) {
       // bias and the time-embedding row of the tile's image -> LDS by DMA (256-byte pieces, one wave each)
@@ -366,7 +468,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
     if (nk > 0) {
       // ---- prologue: chunk A of the first period -> halo buffer 0 (+ gamma | beta), weights of K-tile 0 and pieces 0..2 of K-tile 1
 #pragma unroll
-      for (int j = 0; j < 4; ++j) stage_h(j, 2 * pr0, OFF_H0);
+      for (int j = 0; j < 4; ++j) stage_h(j, 2 * pr0, OFF_H0, true);
       if (GN) stage_gb(2 * pr0, 0);
       begin_stage();
 #pragma unroll
@@ -374,6 +476,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
       begin_stage();
       stage_b(0, oth);
       stage_b(1, oth);
+      stage_b(2, oth);
       if (GN) {
         // (mean, rstd) per group of the tile's image: the fp64 combine of gn_apply_kernel's prologue, same order -> same bits
         if (tid < 256) {
@@ -444,15 +547,21 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
           }
         }
       }
-      wait_vm<2>();                                    // halo chunk, gamma | beta, bias / row vector and K-tile 0 have landed
+      wait_vm<3>();                                    // halo chunk, gamma | beta, bias / row vector and K-tile 0 have landed
       if (GN) {
         lds_barrier();
         make_ss(2 * pr0, 0);
         lds_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) transform(j, OFF_H0, 0);
+        for (int hs = 0; hs < 8; ++hs) {
+          tr_issue(hs, OFF_H0, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          tr_finish(hs);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      addr4(ic<0>{}, ic<0>{});
       __builtin_amdgcn_s_barrier();
       if (wm == 1) __builtin_amdgcn_s_barrier();       // the wm = 1 group runs one barrier behind
       for (int pr = 0; pr < npr; ++pr) {
@@ -494,7 +603,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
         for (int j = 0; j < FN; ++j) {
           const int n = cbn * BN + ewn * (16 * FN) + j * 16 + efg * 4;
           if (n >= p.N) continue;
-          *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          const f32x4 c = j < 4 ? acc[i][j < 4 ? j : 0] : accv[i];
+          *reinterpret_cast<float4*>(ws + (long long)m * p.N + n) = make_float4(c[0], c[1], c[2], c[3]);
         }
       }
     } else {
@@ -523,7 +633,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const SaspaGemmParams p,
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
-            const f32x4& c = acc[qt * 4 + i][j];
+            const f32x4 c = j < 4 ? acc[qt * 4 + i][j < 4 ? j : 0] : accv[qt * 4 + i];
             float v[4] = {c[0] + add[j].x, c[1] + add[j].y, c[2] + add[j].z, c[3] + add[j].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
@@ -697,13 +807,16 @@ extern "C" int saspa_conv3x3_halo(const SaspaGemmParams* pp, const SaspaConvGnPa
   dim3 grid(gx, ks, 1);
   SaspaConvGnParams g0 = {};
   const SaspaConvGnParams& g = gp ? *gp : g0;
+  const bool reg = (p.wout % 16) == 0;
+#define HALO_LAUNCH(F, GNF, R) hipLaunchKernelGGL((conv_halo_kernel<F, GNF, R>), grid, dim3(512), 0, s, p, g, geo)
   if (fn == 5) {
-    if (gp) hipLaunchKernelGGL((conv_halo_kernel<5, true>), grid, dim3(512), 0, s, p, g, geo);
-    else hipLaunchKernelGGL((conv_halo_kernel<5, false>), grid, dim3(512), 0, s, p, g, geo);
+    if (gp) { if (reg) HALO_LAUNCH(5, true, true); else HALO_LAUNCH(5, true, false); }
+    else { if (reg) HALO_LAUNCH(5, false, true); else HALO_LAUNCH(5, false, false); }
   } else {
-    if (gp) hipLaunchKernelGGL((conv_halo_kernel<4, true>), grid, dim3(512), 0, s, p, g, geo);
-    else hipLaunchKernelGGL((conv_halo_kernel<4, false>), grid, dim3(512), 0, s, p, g, geo);
+    if (gp) { if (reg) HALO_LAUNCH(4, true, true); else HALO_LAUNCH(4, true, false); }
+    else { if (reg) HALO_LAUNCH(4, false, true); else HALO_LAUNCH(4, false, false); }
   }
+#undef HALO_LAUNCH
   SASPA_CHECK_LAUNCH();
   if (ks > 1) {
     SaspaGemmParams q = p;

@@ -1062,7 +1062,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   // A-stationary kernel (saspa_gemm_as.hip): pointwise bf16 layers with K = 320 and enough rows to fill the chip; the only
   // kernel that takes a fused LayerNorm / a transposed second output
   if constexpr (sizeof(T) == 2) {
-    if (p.variant == SASPA_GEMM_AS) return saspa_gemm_as_launch(p, s);
+    if (p.variant == SASPA_GEMM_AS) return p.defer_reduce ? SASPA_ERANGE : saspa_gemm_as_launch(p, s);      // (no slabs on this kernel)
     if (p.variant == SASPA_GEMM_AUTO && saspa_gemm_as_ok(p)) {
       // a fused LayerNorm / transposed tail exists on this kernel only; otherwise it is taken where it measured faster than the
       // tiled / wave-specialised kernels (tools/as_bench.py): whole rounds of 256-row blocks, or -- with a ragged last round
@@ -1074,6 +1074,12 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   }
   if (p.ln_gamma || p.out_t || p.variant == SASPA_GEMM_AS) return SASPA_ERANGE;
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;
+  // ABI 18 deferred reduce: the caller will hand `workspace` to saspa_splitk_groupnorm, which sums exactly p.ksplit slabs.  A
+  // launch that ends up on ONE slice (or on a kernel that writes no slabs) would leave the workspace uninitialised and the
+  // consumer would normalise garbage without any error: every branch below that drops the K split is closed to such a call,
+  // and a call that cannot be split at all fails here (round-4 advisor finding).
+  const bool must_split = p.defer_reduce != 0;
+  if (must_split && (ksplit <= 1 || p.act == SASPA_ACT_GEGLU || p.N <= 32 || p.variant == SASPA_GEMM_WS)) return SASPA_ERANGE;
   const bool n160 = (p.N % 160) == 0;
   if (p.gn_stats) {
     // statistics need the LDS-staged bf16 epilogue on 160 / 320-column tiles of 128 / 256 rows (saspa_gemm checked the
@@ -1090,7 +1096,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
         // a twin launch beside this one (sharing): a whole round of the HALF chip is 128 tiles, whatever K (tools/twin_sweep.py)
         if (model_g && p.sharing && ksplit == 1 && t >= 96) return saspa_gemm_pp_launch(p, s, 1, 5);
         if (model_g && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, 5);
-        if (t >= (model_g ? 144 : 192) && (!model_g || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, 5);
+        if (!must_split && t >= (model_g ? 144 : 192) && (!model_g || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, 5);
         static const bool wide_ks_g = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);
         if (wide_ks_g && ksplit > 1 && p.K >= 4096 && t >= 24 && t * ksplit >= 128) return saspa_gemm_pp_launch(p, s, ksplit, 5);
       }
@@ -1158,7 +1164,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
         // ... unless the tiles are just over a whole number of rounds (264 / 288 tiles of the fused Q|K|V projection of the 16x22 /
         // 16x24 level: two rounds at 52-56 %, 99 us against 81 on the 4-wave tiles): then the finer tiles below
         const bool ragged = model && t > 256 && t * 100 < ((t + 255) / 256) * 256 * 65;
-        if (!ragged && t >= (model ? 144 : 192) && (!model || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, fn);
+        if (!must_split && !ragged && t >= (model ? 144 : 192) && (!model || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, fn);
         // fewer wide tiles than CUs but a long K (the 3x3 convs of the 32x32 / 16x16 levels): the wide kernel on K
         // slices -- measured 1.17-1.45x the 128x160 kernel at M = 16 384 / 4 096 (tools/conv_variant_sweep.py)
         static const bool wide_ks = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);   // A/B knob

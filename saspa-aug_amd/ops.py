@@ -273,9 +273,14 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
             q.act, q.y, q.ldy = int(gact), _ptr(out), _pitch4(out)
             if p.ksplit > 1 and lib.saspa_splitk_groupnorm_eligible(C.byref(p), C.byref(q)):
                 p.defer_reduce = 1
-                _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv, deferred reduce)"), meta)
-                _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(q), _stream()), "saspa_splitk_groupnorm")
-                return out
+                # SASPA_ERANGE: the dispatch would run this problem on ONE slice / a kernel without slabs (a variant pin, an A/B
+                # knob): nothing was launched, fall back to conv + groupnorm below
+                rc = _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: lib.saspa_gemm(C.byref(p), _stream()), meta)
+                if rc == 0:
+                    _launch("splitk_gn", 0.0, lambda: _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(q), _stream()), "saspa_splitk_groupnorm"))
+                    return out
+                if rc != -3:
+                    _lib.check(rc, "saspa_gemm(conv, deferred reduce)")
             p.ksplit, p.workspace, p.defer_reduce = 1, None, 0
         h = conv(x, w, bias, kh=kh, kw=kw, stride=stride, pad=pad, upsample=upsample, x2=x2, rowvec=rowvec, residual=residual, alpha=alpha,
                  act=act, out=out, n_out=n_out, variant=variant, korder=korder, ksplit=ksplit, out_hw=out_hw, gn_unit=gn_unit)
@@ -287,8 +292,11 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
 
 
 def halo_conv_enabled():
-    """SASPA_HALO=0: the resnet convs run as GroupNorm apply + im2col conv again (A/B knob for saspa_conv3x3_halo)."""
-    return os.environ.get("SASPA_HALO", "1") != "0"
+    """SASPA_HALO=1: ResnetBlock2D's norm -> SiLU -> conv pairs of the large levels run as ONE launch each on saspa_conv3x3_halo
+    (GroupNorm applied to the conv's input tile in LDS).  OFF by default: built, parity-tested (tests/test_conv_halo_gpu.py) and
+    measured in round 5 -- at parity with GroupNorm apply + im2col conv per launch and 1.4 % SLOWER end to end
+    (profiles/r5_halo_conv.txt), so the two-launch path stays the production one."""
+    return os.environ.get("SASPA_HALO", "0") == "1"
 
 
 def _gn_source_stats(x, x2, groups):
@@ -317,7 +325,7 @@ def conv_gn(x, gn, w32, bias=None, *, x2=None, rowvec=None, residual=None, alpha
     groups, eps, act): the conv's only consumer is that GroupNorm and the conv runs on K slices -> saspa_splitk_groupnorm sums the
     slabs and normalises (as ops.conv(fuse_gn=...))."""
     _check_dev(x, w32, bias, x2, rowvec, residual, out)
-    if x.dtype != torch.bfloat16 or not halo_conv_enabled():
+    if x.dtype != torch.bfloat16:
         return None
     lib = _lib.load()
     b, h, wd, c0 = x.shape

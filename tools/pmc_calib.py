@@ -62,7 +62,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "table":
     if len(sys.argv) > 4:
         import json
         # {kernel-name substring: measured FETCH_SIZE / known bytes}; the 3x3 case of the 8-wave kernel is listed for the record
-        json.dump({k.replace(" conv", ""): v for k, v in factors.items() if " conv" not in k}, open(sys.argv[4], "w"), indent=1)
+        # {kernel-name substring: measured FETCH_SIZE / known bytes}.  The 3x3 instantiations of the 8-wave kernel get their own
+        # entries (matched before the family's: tools/pmc_traffic_json.py takes the first key a name contains, most specific first)
+        out = {k.replace(" conv", ""): v for k, v in factors.items() if " conv" not in k}
+        if "gemm_pp_kernel conv" in factors:
+            cv = factors["gemm_pp_kernel conv"]
+            out = {"gemm_pp_kernel<5, false": cv, "gemm_pp_kernel<4, false": cv, "gemm_pp_kernelILi5ELb0": cv, "gemm_pp_kernelILi4ELb0": cv,
+                   "conv_halo_kernel": cv, **out}
+        json.dump(out, open(sys.argv[4], "w"), indent=1)
     sys.exit(0)
 
 import torch  # noqa: E402

@@ -6,7 +6,7 @@ beyond-L2 read bytes are known by construction): `calibration.json` = {family su
 totals with the read side uncorrected (`raw`, a lower bound), doubled everywhere (`x2`, an upper bound) and corrected per kernel
 by its calibrated factor (`best`), plus the same three per kernel name (`by_kernel`)."""
 import csv, json, re, sys
-FAMILY = ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_kernel", "gemm_ws_kernel", "gemm_as_kernel", "xattn_block_kernel")
+FAMILY = ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_kernel", "gemm_ws_kernel", "gemm_as_kernel", "xattn_block_kernel", "conv_halo_kernel")
 calib = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
 def short(name):
     return re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+|void ", "", name)[:64]
@@ -27,9 +27,12 @@ by_kernel, tot = {}, dict(n=0, raw=0.0, x2=0.0, best=0.0, w=0.0)
 for name, (fb, n) in sorted(fe.items(), key=lambda kv: -kv[1][0]):
     wb = wr.get(name, [0.0, 0])[0]
     f = factor(name)
-    corr = 2.0 if (f is not None and f < 0.75) else (1.0 if f is not None else 2.0)     # uncalibrated kernels: the guide's x2
+    # `best`: the read side divided by the factor MEASURED for the kernel (0.50 - 0.54 for the LDS-DMA readers of pointwise
+    # operands = the guide's x2; 0.77 for the 3x3 instantiations of the 8-wave kernel, whose reads are 128-byte rows the counter
+    # tallies closer to their size); uncalibrated kernels: the guide's x2
+    corr = (1.0 / f if f > 0.05 else 2.0) if f is not None else 2.0
     by_kernel[name] = dict(launches=n, fetch_raw_MB=round(fb / n / 1e6, 2), write_MB=round(wb / n / 1e6, 2),
-                           fetch_factor_measured=f, correction=("x2" if corr == 2.0 else "none") + ("" if f is not None else " (uncalibrated)"),
+                           fetch_factor_measured=f, correction=(f"x{corr:.2f}") + ("" if f is not None else " (uncalibrated)"),
                            hbm_MB_per_launch=round((corr * fb + wb) / n / 1e6, 2))
     tot["n"] += n; tot["raw"] += fb; tot["x2"] += 2 * fb; tot["best"] += corr * fb; tot["w"] += wb
 n = max(tot["n"], 1)

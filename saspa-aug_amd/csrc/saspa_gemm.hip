@@ -1041,6 +1041,10 @@ static bool ws_round_ok(long long t) {
   return t * 100 >= rounds * 256 * 85;
 }
 
+// wide (256-row) tiles from which a launch with a twin beside it (SaspaGemmParams.sharing) runs un-split on the 8-wave kernel:
+// one constant for dispatch() and saspa_gemm_suggest_ksplit
+constexpr long long kTwinWholeRound = 96;
+
 // ncu: CUs the launch may count on -- 256, or 128 when a twin launch shares the chip (SaspaGemmParams.sharing)
 static int pp_choose_ksplit(long long t, int ktiles, long long mn, int fn, int ncu = 256) {
   const double c0 = 20.0, c1 = fn == 5 ? 1.34 : 1.07;
@@ -1094,7 +1098,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
         const long long t = (long long)((p.M + 255) / 256) * (p.N / 320);
         static const bool model_g = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);
         // a twin launch beside this one (sharing): a whole round of the HALF chip is 128 tiles, whatever K (tools/twin_sweep.py)
-        if (model_g && p.sharing && ksplit == 1 && t >= 96) return saspa_gemm_pp_launch(p, s, 1, 5);
+        if (model_g && p.sharing && ksplit == 1 && t >= kTwinWholeRound) return saspa_gemm_pp_launch(p, s, 1, 5);
         if (model_g && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, 5);
         if (!must_split && t >= (model_g ? 144 : 192) && (!model_g || ksplit == 1)) return saspa_gemm_pp_launch(p, s, 1, 5);
         static const bool wide_ks_g = !(getenv("SASPA_GEMM_WIDE_SPLITK") && atoi(getenv("SASPA_GEMM_WIDE_SPLITK")) == 0);
@@ -1155,7 +1159,7 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
         // a twin launch of the same shape shares the chip (SaspaGemmParams.sharing): 96+ wide tiles are a whole round of this
         // launch's half, for every K the wide kernel takes -- pair times of tools/twin_sweep.py (profiles/r4_twin_sweep.txt):
         // (16384, 640, 2560) + residual 112 vs 152 us, conv (16384, 640, 2880) 106 vs 139, conv (16384, 640, 5760) 183 vs 270
-        if (model && p.sharing && ksplit == 1 && t >= 96) return saspa_gemm_pp_launch(p, s, 1, fn);
+        if (model && p.sharing && ksplit == 1 && t >= kTwinWholeRound) return saspa_gemm_pp_launch(p, s, 1, fn);
         // long K, one slice chosen by the cost model (suggest_ksplit) and at least half the CUs busy: still the wide kernel
         if (model && ksplit == 1 && p.K >= 4096 && t >= 128) return saspa_gemm_pp_launch(p, s, 1, fn);
         // 3/4 of a wave of tiles or more: no split-K.  (144 <= t < 192 is the 512x704 / 512x768 buckets' 32x44 / 32x48 level:
@@ -1235,7 +1239,9 @@ extern "C" int saspa_gemm_suggest_ksplit(const SaspaGemmParams* pp) {
         // least half the CUs busy (dispatch() applies the same rule).  With a twin launch beside it (sharing) the launch
         // counts on half the chip: 128 tiles need no slices, 64 tiles two instead of four
         const int ks = pp_choose_ksplit(t, ktiles, (long long)p.M * p.N, fn, p.sharing ? 128 : 256);
-        if (ks > 1 || t >= (p.sharing ? 64 : 128)) return ks;
+        // one slice only where dispatch() really takes the wide kernel un-split (kTwinWholeRound tiles with a twin, 128 alone);
+        // below that a one-slice answer would land on the 4-wave tiles un-split (round-4 advisor finding): fall through
+        if (ks > 1 || t >= (p.sharing ? kTwinWholeRound : 128)) return ks;
       }
     }
   }

@@ -343,7 +343,7 @@ class _Net:
             a = t + ".attn2"
             k = ops.linear(ctx, self.p[a + ".k.w"])                     # [B,77,C]
             vt = project_vt(ctx, self.p[a + ".v.w"], n)                 # [B,C,80]
-            if t in self.xattn_blocks and xattn_enabled():
+            if t in self.xattn_blocks and xattn_enabled() and n <= 96:    # (longer contexts: the three-launch path of transformer())
                 # the same K / V cut into the MFMA operand fragments of saspa_xattn_block (time-invariant, like K / V^T themselves)
                 kf, vf = W.xattn_kv_fragments(k, vt[:, :, :n].transpose(1, 2).contiguous())
                 self.ctx_kv[t] = (k, vt, n, kf, vf)

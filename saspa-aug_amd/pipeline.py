@@ -863,8 +863,12 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
             nc, hw = self.cfgs["unet"]["out_channels"], (hh // 8) * (ww // 8)
             state = torch.zeros((3, b) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype) if unipc else None
             for i, t in enumerate(ts):
-                mid, skips = self.unet.encode(x, i)
-                skips2, mid2 = self.controlnet.forward(x, i, cemb, controlnet_conditioning_scale, skips, mid)
+                # the same launches, with the same dispatch decisions, as the two-branch graph step (_StepGraph._step): the paired
+                # encoders carry the shared-chip hint (ops.twin_branch) -- except under a launch recorder (every launch alone)
+                with ops.twin_branch(fork_enabled() and ops._RECORDER is None):
+                    cmid, cfeats = self.controlnet.encode(x, i, conv_in_residual=cemb)
+                    mid, skips = self.unet.encode(x, i)
+                skips2, mid2 = self.controlnet.zero_convs(cmid, cfeats, controlnet_conditioning_scale, skips, mid)
                 self.unet.decode(mid2, skips2, i, out=eps)
                 if unipc and cfg:
                     ops.cfg_unipc_step(eps, x, state, b, hw, nc, guidance_scale, row=rows[i])

@@ -44,6 +44,26 @@ def test_host_side_argument_validation_needs_no_gpu():
     p.c0 = p.K = p.lda0 = p.ldw = 16
     p.K = 32
     assert lib.saspa_gemm(C.byref(p), None) == -3                    # K != kh*kw*(c0+c1)
+    # ABI 18 deferred reduce without K slices (no workspace): nothing would write the slabs the consumer sums -> refused
+    p.K = p.c0 = p.lda0 = p.ldw = 16
+    p.nb1 = p.nb2 = 1
+    p.alpha = 1.0
+    assert lib.saspa_gemm_suggest_ksplit(C.byref(p)) == 1
+    p.defer_reduce, p.ksplit, p.workspace = 1, 1, None
+    assert lib.saspa_gemm(C.byref(p), None) == -3
+    p.defer_reduce = 0
+    # ABI 19: the halo conv's eligibility and K-slice arithmetic are host-side
+    h = _lib.GemmParams()
+    h.dtype, h.kh, h.kw, h.stride, h.pad, h.batch, h.hin, h.win, h.hout, h.wout = 0, 3, 3, 1, 1, 2, 16, 16, 16, 16
+    h.c0, h.c1, h.N, h.K, h.M, h.ldw, h.lda0, h.ldo, h.korder, h.nb1, h.nb2 = 320, 0, 640, 2880, 512, 2880, 320, 640, 2, 1, 1
+    assert lib.saspa_conv3x3_halo_eligible(C.byref(h), None) == 1
+    assert lib.saspa_conv3x3_halo_ksplit(C.byref(h), 3) == 3 and lib.saspa_conv3x3_halo_ksplit(C.byref(h), 4) == 3   # 5 chunk pairs: 2 + 2 + 1
+    h.korder = 1
+    assert lib.saspa_conv3x3_halo_eligible(C.byref(h), None) == 0                                                  # im2col packing
+    h.korder, h.hin, h.hout = 2, 8, 8
+    h.M = 2 * 8 * 16
+    assert lib.saspa_conv3x3_halo_eligible(C.byref(h), None) == 0                                                  # 128 pixels per image
+    assert lib.saspa_conv3x3_halo(C.byref(h), None, None) == -1                                                    # null operands
     q = _lib.AttnParams()
     assert lib.saspa_flash_attn_bf16(C.byref(q), None) == -1
     assert lib.saspa_canny(None, None, None, 1, 8, 8, 1, 2, None) == -1

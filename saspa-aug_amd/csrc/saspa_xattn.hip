@@ -85,19 +85,22 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const SaspaXattnBlo
   // ---- W slices through the ring (as gemm_as_kernel): slice t = rows [64 t, 64 t + 64) of the stacked [Wq' ; Wo'] ----
   const rsrc_t rsw = make_rsrc(p.w);
   const rsrc_t rsb = make_rsrc(p.bias);
-  int dn[XA_NDMA], dkc[XA_NDMA];
-#pragma unroll
-  for (int i = 0; i < XA_NDMA; ++i) {
-    const int q = (wave * XA_NDMA + i) * 64 + lane;
-    const int n = q / XA_PITCH, kcp = q - n * XA_PITCH;
-    dn[i] = n;
-    dkc[i] = kcp ^ ((n >> 1) & 7);
-  }
+  // lane id re-derived at the point of use behind an asm barrier (2 VALU): the per-piece (row, chunk) pairs below are lane
+  // constants the compiler would otherwise keep in 10 registers across the whole kernel, which has none to spare
+  auto lane_now = []() __attribute__((always_inline)) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
   const int ndma = XA_NDMA + (wave == 7 ? 1 : 0);
   auto dma_piece = [&](int step, int i) __attribute__((always_inline)) {
     const bool real = step < XA_NSL;
     if (i < XA_NDMA) {
-      const unsigned off = real ? (unsigned)((step * XA_BN + dn[i]) * p.ldw * 2 + dkc[i] * 16) : kInvalid;
+      const int q = (wave * XA_NDMA + i) * 64 + lane_now();
+      const int n = (int)(((unsigned)q * 52429u) >> 21);                // q / 40 for q < 2560 (exact: 52429 = ceil(2^21 / 40))
+      const int kcp = q - n * XA_PITCH;
+      const int dkc = kcp ^ ((n >> 1) & 7);
+      const unsigned off = real ? (unsigned)((step * XA_BN + n) * p.ldw * 2 + dkc * 16) : kInvalid;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(lds + (step % XA_RING) * XA_STAGE + (wave * XA_NDMA + i) * 64), 16, (int)off, 0, 0, 0);
     } else if (wave == 7) {
       const unsigned off = (real && lane < 16) ? (unsigned)((step * XA_BN + 4 * lane) * 4) : kInvalid;
@@ -228,6 +231,15 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const SaspaXattnBlo
     mark2 = issued;
     pack_block(acc[0], qf[4 * step], qf[4 * step + 1]);
     pack_block(acc[1], qf[4 * step + 2], qf[4 * step + 3]);
+    // pin the PACKED fragments here: left alone, LLVM sinks the bf16 conversion to the heads that consume it and keeps (spills)
+    // the fp32 accumulator values instead -- twice the registers, reloaded behind vmcnt(0) in the attention stage
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // (through a FLOAT vector: integer 4-vectors as asm in/out operands get wrong sub-registers from hipcc 7.2)
+      f32x4 t = __builtin_bit_cast(f32x4, qf[4 * step + q]);
+      asm volatile("" : "+v"(t));
+      qf[4 * step + q] = __builtin_bit_cast(u32x4, t);
+    }
     mark0 = mark1;
     mark1 = mark2;
   }

@@ -629,6 +629,9 @@ __global__ __launch_bounds__(256) void flash_attn_v2_kernel(const SaspaAttnParam
 // ABL (diagnostics, `make ABLATION=1` + SASPA_ATTN_ABLATE only; 0 in the shipped library): 1 no exponentials, 2 no MFMAs,
 // 4 no LDS fragment reads, 8 no staging (global loads / LDS stores / barriers), 16 stamps (s_memtime / s_memrealtime of
 // the tile loop of every workgroup's thread 0 behind the output tensor: tools/attn_ablate.py)
+#ifndef SASPA_ATTN_PF
+#define SASPA_ATTN_PF 2
+#endif
 template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0, bool RM = false>
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAttnParams p) {
   // RM: V row-major, read through ds_read_b64_tr_b16 (see lds_read_tr16 at the top of the file)
@@ -880,22 +883,24 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
         const int q = i - NPV, kb = q / KS, sx = q - kb * KS;
         return *reinterpret_cast<const u32x4*>(ksm + ((kb * 32 + r) * KSLOTS + 2 * sx + h) * 16);
       };
-      u32x4 fr[3];
-      fr[0] = frag(0);
-      fr[1] = frag(1);
+      // operand fragments are read PF MFMA slots ahead of their use (SASPA_ATTN_PF, default 2: round 3's choice)
+      constexpr int PF = SASPA_ATTN_PF;
+      u32x4 fr[PF + 1];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = frag(i);
       int u = 0;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        if (i + 2 < NM) fr[(i + 2) % 3] = frag(i + 2);
+        if (i + PF < NM) fr[(i + PF) % (PF + 1)] = frag(i + PF);
         if (i < NPV) {
           const int ks = i / NB, nb = i % NB, kb = ks >> 1, half = ks & 1;
           const u32x4 pf = {Pp[kb][4 * half + 0], Pp[kb][4 * half + 1], Pp[kb][4 * half + 2], Pp[kb][4 * half + 3]};
-          if (ABL & 2) { asm volatile("" ::"v"(fr[i % 3]), "v"(pf)); }
-          else acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % 3]), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
+          if (ABL & 2) { asm volatile("" ::"v"(fr[i % (PF + 1)]), "v"(pf)); }
+          else acc_o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % (PF + 1)]), __builtin_bit_cast(bf16x8, pf), acc_o[nb], 0, 0, 0);
         } else {
           const int q = i - NPV, kb = q / KS, sx = q - kb * KS;
-          if (ABL & 2) { asm volatile("" ::"v"(fr[i % 3])); if (sx == 0) Sn[kb] = negm; }
-          else Sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % 3]), __builtin_bit_cast(bf16x8, qf[sx]),
+          if (ABL & 2) { asm volatile("" ::"v"(fr[i % (PF + 1)])); if (sx == 0) Sn[kb] = negm; }
+          else Sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i % (PF + 1)]), __builtin_bit_cast(bf16x8, qf[sx]),
                                                                 sx == 0 ? negm : Sn[kb], 0, 0, 0);
         }
         const int nu = NU / NM + (i < NU % NM ? 1 : 0);

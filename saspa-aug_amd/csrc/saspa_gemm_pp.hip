@@ -53,8 +53,11 @@ __device__ __forceinline__ void mma(const u32x4& wf, const u32x4& xf, f32x4& acc
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int FN, bool PW, bool UP, bool ONEBAR>
+// LOOP: 0 = two-barrier ping-pong, four 20-MFMA phases per K-tile; 1 = one barrier per phase, asymmetric programs (round 3,
+// slower, A/B arm); 2 = two-barrier ping-pong with TWO 40-MFMA phases per K-tile (round 5: half the pipe hand-offs)
+template <int FN, bool PW, bool UP, int LOOP>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, const int ntiles_abl, const int npart8) {
+  constexpr bool ONEBAR = LOOP == 1;
   // diagnostic ablation (tools/gemm_ablate.py, `make ABLATION=1` only): bits 28..31 of the tile count
   //   1: no MFMA   2: no fragment reads   4: no DMA issue   8: no barriers;  bits 24..26 (SASPA_GEMM_EPI_ABLATE): epilogue
   const int ntiles = ntiles_abl & 0x00ffffff;
@@ -544,6 +547,98 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 #ifdef SASPA_GEMM_ABLATION
         if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
 #endif
+      } else if (LOOP == 2) {
+        // ---- long ping-pong (round 5): the loop below with its phases merged in pairs ----
+        // What the two-barrier hand-off costs does not depend on the length of the MFMA block it separates (measured: 424
+        // cycles per interval for MFMAs + barriers against 320 of MFMA, DESIGN 7 / EXPERIMENTS), so a K-tile is cut into TWO
+        // intervals of 40 MFMAs (Q0: slices 0, 1; Q1: slices 2, 3) instead of four of 20.  No more fragment registers than
+        // before: the MFMAs of a slice run row-fragment-major (i outer), and the A fragments of the interval's SECOND slice are
+        // read inside the block into the registers its first slice has just released (10 MFMAs = 160 cycles of cover each).
+        // Per accumulator the K order is unchanged (kk = 0, then 1): bit-identical to the other loops.
+        // DMA schedule: Q1 of tile t sends A slices 0, 1 and ALL weight pieces of tile t+2 into `cur` (the weight slot is free
+        // once both groups have read tile t's B fragments: retired before Q0's first barrier; slices 0, 1 were read in Q0),
+        // Q0 of tile t sends A slices 2, 3 of tile t+1 into `oth` (read in Q1 of tile t-1).  Every piece is two intervals in
+        // flight: one counted wait per interval, vmcnt(4 + FN), ahead of its first barrier, covers what the NEXT interval reads.
+        auto stage_q1 = [&](const int buf) __attribute__((always_inline)) {
+          stage_a(0, buf);
+          stage_a(1, buf);
+#pragma unroll
+          for (int i = 0; i < FN; ++i) stage_b(i, buf);
+        };
+        auto read_a2 = [&](const int i, const int S) __attribute__((always_inline)) {
+          xa[i][0] = lds[ra0 + (S * 32 + i * 16) * 8];
+          xa[i][1] = lds[ra1 + (S * 32 + i * 16) * 8];
+        };
+        auto mma_row = [&](const int i, const int R) __attribute__((always_inline)) {
+          if (abl & 1) {
+            asm volatile("" ::"v"(xa[i][0])); asm volatile("" ::"v"(xa[i][1]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(wb[j][0])); asm volatile("" ::"v"(wb[j][1])); }
+            return;
+          }
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mma(wb[j][kk], xa[i][kk], acc[R][j]);
+        };
+        auto qphase = [&](const int Q) __attribute__((always_inline)) {
+          if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_setprio(1);
+          mma_row(0, 4 * Q + 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(abl & 2)) read_a2(0, 2 * Q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_row(1, 4 * Q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(abl & 2)) read_a2(1, 2 * Q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_row(0, 4 * Q + 2);
+          mma_row(1, 4 * Q + 3);
+          __builtin_amdgcn_s_setprio(0);
+          if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+        };
+        begin_stage();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) stage_slice(s, cur);
+        begin_stage();
+        stage_q1(oth);
+        wait_vm<2 + FN>();                             // tile 0 has landed; tile 1 (slices 0, 1 + weights) stays in flight
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();     // the wm = 1 group runs one barrier behind
+#ifdef SASPA_GEMM_ABLATION
+        if (stamp) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        for (int t = 0; t < nk; ++t) {
+          // ---- Q0: B fragments + slice 0 of tile t; slices 2, 3 of tile t+1 -> oth ----
+          if (!(abl & 2)) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              wb[j][0] = lds[rb0 + j * 16 * 8];
+              wb[j][1] = lds[rb1 + j * 16 * 8];
+            }
+            __builtin_amdgcn_sched_barrier(0);         // B reads are issued (and counted) before the A reads
+            read_a2(0, 0);
+            read_a2(1, 0);
+          }
+          if (!(abl & 4)) { stage_a(2, oth); stage_a(3, oth); }
+          wait_vm<4 + FN>();                           // slices 2, 3 of tile t (Q1 reads them)
+          asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");   // B reads retired: the other group may restage the slot in its Q1
+          qphase(0);
+          begin_stage();
+          // ---- Q1: slice 2 of tile t; slices 0, 1 + weights of tile t+2 -> cur ----
+          if (!(abl & 2)) { read_a2(0, 2); read_a2(1, 2); }
+          if (!(abl & 4)) stage_q1(cur);
+          wait_vm<4 + FN>();                           // slices 0, 1 + weights of tile t+1 (the next Q0 reads them)
+          qphase(1);
+          const int d = oth - cur;
+          ra0 += d; ra1 += d; rb0 += d; rb1 += d;
+          cur += d;
+          oth -= d;
+        }
+#ifdef SASPA_GEMM_ABLATION
+        if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        if (wm == 0) __builtin_amdgcn_s_barrier();     // barrier counts of the two groups match again
       } else {
       // ---- prologue: tile 0 complete, slices 0..2 of tile 1 in flight ----
       begin_stage();
@@ -865,7 +960,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   }
 }
 
-template <int FN, bool ONEBAR>
+template <int FN, int ONEBAR>
 int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 256, BN = 64 * FN;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
@@ -912,16 +1007,22 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
 
 int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn) {
   if (!saspa_gemm_pp_eligible(p)) return SASPA_ERANGE;
-  // K loop flavour: SASPA_GEMM_PP_LOOP=1 selects the one-barrier-per-phase asymmetric loop (fn 14 / 15) instead of the
-  // two-barrier ping-pong loop.  Built and measured in round 3 (tools/pp_ab.py, profiles/r3_pp_ab_v*.txt): bit-identical
-  // and 12 - 30 % SLOWER on every shape, with either DMA schedule -- kept as an opt-in A/B arm, read per launch.
+  // K loop flavour (read per launch; all three are bit-identical: same MFMA order per accumulator):
+  //   SASPA_GEMM_PP_LOOP=2 (default since round 5)  two-barrier ping-pong, TWO 40-MFMA intervals per K-tile: +2 ... +8 % on every
+  //                         shape against =0 (tools/pp_ab.py, profiles/r5_pp_long_ab.txt)
+  //   =0  two-barrier ping-pong, four 20-MFMA phases per K-tile (rounds 2 - 4)
+  //   =1  one barrier per phase, asymmetric programs (round 3: 12 - 30 % SLOWER, profiles/r3_pp_ab_v*.txt; A/B arm only)
   if (fn == 4 || fn == 5) {
     const char* e = getenv("SASPA_GEMM_PP_LOOP");
-    if (e && atoi(e) == 1) fn += 10;
+    const int loop = e ? atoi(e) : 2;
+    if (loop == 1) fn += 10;
+    if (loop == 2) fn += 20;
   }
-  if (fn == 5) return launch_pp<5, false>(p, s, ksplit);
-  if (fn == 4) return launch_pp<4, false>(p, s, ksplit);
-  if (fn == 15) return launch_pp<5, true>(p, s, ksplit);
-  if (fn == 14) return launch_pp<4, true>(p, s, ksplit);
+  if (fn == 5) return launch_pp<5, 0>(p, s, ksplit);
+  if (fn == 4) return launch_pp<4, 0>(p, s, ksplit);
+  if (fn == 15) return launch_pp<5, 1>(p, s, ksplit);
+  if (fn == 14) return launch_pp<4, 1>(p, s, ksplit);
+  if (fn == 25) return launch_pp<5, 2>(p, s, ksplit);
+  if (fn == 24) return launch_pp<4, 2>(p, s, ksplit);
   return SASPA_ERANGE;
 }

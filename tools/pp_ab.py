@@ -1,6 +1,8 @@
-"""A/B of the two K loops of the 8-wave wide GEMM (saspa_gemm_pp.hip) in ONE process, interleaved rounds: the two-barrier
-ping-pong loop (default) against the one-barrier-per-phase asymmetric loop (SASPA_GEMM_PP_LOOP=1), on the conv / linear
-shapes the pipeline sends to that kernel; outputs must be bit-identical (same MFMA order per accumulator)."""
+"""A/B of the K loops of the 8-wave wide GEMM (saspa_gemm_pp.hip) in ONE process, interleaved rounds: the two-barrier
+ping-pong loop with four 20-MFMA phases per K-tile (SASPA_GEMM_PP_LOOP=0) against the one-barrier-per-phase asymmetric loop
+(=1, round 3) and the two-barrier loop with two 40-MFMA phases per K-tile (=2, round 5), on the conv / linear shapes the
+pipeline sends to that kernel; outputs must be bit-identical (same MFMA order per accumulator).
+usage: python tools/pp_ab.py [704] [arms=pingpong,long]"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
@@ -16,6 +18,9 @@ if "704" in sys.argv:
     shapes = [(16, 64, 88, 320, 320, 3, None), (16, 64, 88, 640, 320, 3, None), (16, 32, 44, 640, 640, 3, None),
               (16, 32, 44, 1280, 640, 3, None), (16, 16, 22, 1280, 1280, 3, None), (16, 16, 22, 2560, 1280, 3, None)]
 ROUNDS, REP = 5, 10
+ALL = {"pingpong": "0", "asym": "1", "long": "2"}
+arms = [a for a in sys.argv[1:] if a.startswith("arms=")]
+ARMS = [(n, ALL[n]) for n in (arms[0][5:].split(",") if arms else ["pingpong", "long"])]
 for (b, h, w_, cin, cout, kind, ks) in shapes:
     taps = 1 if kind in (1, 'g') else 9
     K = taps * cin
@@ -39,9 +44,9 @@ for (b, h, w_, cin, cout, kind, ks) in shapes:
         if kind == 'g':
             return ops.linear(xs[j].view(-1, cin), wt, bias, act=ops.ACT_GEGLU, variant=ops.GEMM_WIDE)
         return ops.linear(xs[j].view(-1, cin), wt, bias, variant=ops.GEMM_WIDE)
-    res, outs = {"pingpong": [], "asym": []}, {}
+    res, outs = {n: [] for n, _ in ARMS}, {}
     for rnd in range(ROUNDS + 1):
-        for name, env in (("pingpong", "0"), ("asym", "1")):
+        for name, env in ARMS:
             os.environ["SASPA_GEMM_PP_LOOP"] = env
             i[0] = 0
             if rnd == 0:
@@ -51,8 +56,8 @@ for (b, h, w_, cin, cout, kind, ks) in shapes:
             for _ in range(REP): f()
             e1.record(); torch.cuda.synchronize()
             if rnd: res[name].append(e0.elapsed_time(e1) * 1000 / REP)
-    same = torch.equal(outs["pingpong"], outs["asym"])
+    same = all(torch.equal(outs[ARMS[0][0]], outs[n]) for n, _ in ARMS[1:])
     fl = 2.0 * M * cout * K
     med = {n: sorted(v)[len(v) // 2] for n, v in res.items()}
     print(f"M={M} N={cout} K={K} kind={kind}: " + "  ".join(f"{n} {med[n]:7.1f} us {fl / med[n] / 1e6:6.0f} TF/s" for n in med)
-          + f"  ratio {med['pingpong'] / med['asym']:.3f}  bit-identical={same}", flush=True)
+          + f"  ratio {med[ARMS[0][0]] / med[ARMS[-1][0]]:.3f}  bit-identical={same}", flush=True)

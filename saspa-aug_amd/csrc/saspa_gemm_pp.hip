@@ -43,6 +43,10 @@ constexpr bool KORDER_ON = false;   // A/B build: the K walk exactly as before A
 constexpr bool KORDER_ON = true;
 #endif
 
+#ifndef SASPA_PP_CT_ABL
+#define SASPA_PP_CT_ABL 0
+#endif
+
 namespace {
 
 typedef bf16_t T;
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
   const unsigned long long sr_entry = __builtin_amdgcn_s_memrealtime();
   const int eabl = (ntiles_abl >> 24) & 7;             // epilogue ablation: 1 = no global stores, 2 = no epilogue at all
 #else
-  constexpr int abl = 0, eabl = 0;
+  // compile-time ablation of the K loop (tools/pp_ct_ablate.py builds one library per value; 0 in the shipped library): the
+  // same bits as above without a run-time test inside the unrolled loop, which changes what it measures
+  constexpr int abl = SASPA_PP_CT_ABL, eabl = 0;
 #endif
   constexpr int BM = 256, BN = 64 * FN, BK = 64, SZ = 2;
   constexpr int STAGE = (BM + BN) * 8;                 // u32x4 per LDS buffer
@@ -325,7 +331,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 
   f32x4 acc[8][FN];
   u32x4 wb[FN][2], xa[2][2];
-#ifdef SASPA_GEMM_ABLATION
+  int dbgv[4] = {0, 0, 0, 0};                          // ablation bit 32 only
+#if defined(SASPA_GEMM_ABLATION) || SASPA_PP_CT_ABL
 #pragma unroll
   for (int j = 0; j < FN; ++j) wb[j][0] = wb[j][1] = u32x4{(unsigned)j, 0u, 0x3f803f80u, 0x3f803f80u};
 #pragma unroll
@@ -581,6 +588,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 #pragma unroll
             for (int j = 0; j < FN; ++j) mma(wb[j][kk], xa[i][kk], acc[R][j]);
         };
+        // ablation bit 32 (compile time, timing library only): per wave, the shader cycles spent between the END of an MFMA
+        // block and the release of the barrier behind it, summed per interval kind -- i.e. how long the matrix pipe's owner
+        // waits for its partner's reads / DMA issue to finish (plus the barrier's own latency); waves 0 and 4 of workgroup 0
+        // leave {sum Q0, sum Q1, loop cycles, intervals} in the first 32 bytes of the output
+        int wsum[2] = {0, 0};
+        long long tloop0 = 0;
+        if (abl & 32) tloop0 = __builtin_amdgcn_s_memtime();
         auto qphase = [&](const int Q) __attribute__((always_inline)) {
           if (!(abl & 8)) __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_s_setprio(1);
@@ -595,7 +609,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
           mma_row(0, 4 * Q + 2);
           mma_row(1, 4 * Q + 3);
           __builtin_amdgcn_s_setprio(0);
+          long long tb = 0;
+          if (abl & 32) { __builtin_amdgcn_sched_barrier(0); tb = __builtin_amdgcn_s_memtime(); }
           if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+          if (abl & 32) {
+            const long long te = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wsum[Q] += (int)(te - tb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         };
         begin_stage();
 #pragma unroll
@@ -639,6 +661,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
         if (stamp) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
 #endif
         if (wm == 0) __builtin_amdgcn_s_barrier();     // barrier counts of the two groups match again
+        if ((abl & 32) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0) {
+          dbgv[0] = wsum[0]; dbgv[1] = wsum[1]; dbgv[2] = (int)(__builtin_amdgcn_s_memtime() - tloop0); dbgv[3] = 2 * nk;
+        }
       } else {
       // ---- prologue: tile 0 complete, slices 0..2 of tile 1 in flight ----
       begin_stage();
@@ -957,6 +982,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
     if (!has_next) break;
     tile = next;
     setup_tile(tile);
+  }
+  if (abl & 32) {
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0) {
+      int* dbg = reinterpret_cast<int*>(p.out) + (wave >> 2) * 4;
+      dbg[0] = dbgv[0]; dbg[1] = dbgv[1]; dbg[2] = dbgv[2]; dbg[3] = dbgv[3];
+    }
   }
 }
 

@@ -144,3 +144,44 @@ def test_auto_dispatch_level0_resnet_conv(dev):
         assert_close(from_nhwc(tiled[i:i + 1]), ref, BF, what=f"level-0 conv image {i} (tiled)")
     # the two kernels sum K in the same tile order per output; they may differ by bf16 rounding only
     assert (wide.float() - tiled.float()).abs().max().item() <= 0.0625
+
+
+LOOP_CASES = [
+    # (kind, B, H, W, Cin, Cout, ksplit): every K-loop flavour must give the SAME bits (same MFMA order per accumulator)
+    ("conv", 2, 24, 24, 128, 256, 1),     # 256-wide tile instantiation
+    ("conv", 1, 40, 40, 192, 640, 1),     # 320-wide tile, 27 K-tiles, ragged M
+    ("conv", 1, 16, 16, 512, 320, 2),     # K slices (fp32 slabs + reduce)
+    ("up", 1, 8, 12, 64, 48, 1),          # nearest x2 + conv
+    ("lin", 300, 1, 1, 64, 320, 1),       # ONE K-tile: prologue and tail only
+    ("lin", 300, 1, 1, 128, 320, 1),      # two K-tiles
+    ("lin", 4096, 1, 1, 1280, 320, 1),
+]
+
+
+@pytest.mark.parametrize("case", LOOP_CASES)
+def test_wide_loop_flavours_bit_identical(dev, monkeypatch, case):
+    """SASPA_GEMM_PP_LOOP (read per launch): 2 = two 40-MFMA intervals per K-tile (default since round 5), 0 = four 20-MFMA
+    phases (rounds 2 - 4), 1 = one barrier per phase (round 3 A/B arm).  The default must equal the others bit for bit and
+    the torch reference within the bf16 tolerance."""
+    kind, b, h, w_, cin, cout, ks = case
+    outs = {}
+    if kind == "lin":
+        x, wt, bias = q(_rand(b, cin, seed=51), BF), q(_rand(cout, cin, seed=52, scale=1 / math.sqrt(cin)), BF), _rand(cout, seed=53)
+        ref = x @ wt.t() + bias
+        run = lambda: ops.linear(x.to(dev, BF), wt.to(dev, BF), bias.to(dev), variant=ops.GEMM_WIDE).float().cpu()
+    else:
+        up = kind == "up"
+        x = q(_rand(b, cin, h, w_, seed=54), BF)
+        wt = q(_rand(cout, cin, 3, 3, seed=55, scale=1 / math.sqrt(9 * cin)), BF)
+        bias = _rand(cout, seed=56)
+        ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x, wt, bias, padding=1)
+        xd, wd = to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF)
+        run = lambda: from_nhwc(ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, upsample=up, variant=ops.GEMM_WIDE, ksplit=ks), cout)
+    for loop in ("2", "0", "1"):
+        monkeypatch.setenv("SASPA_GEMM_PP_LOOP", loop)
+        outs[loop] = run()
+    monkeypatch.delenv("SASPA_GEMM_PP_LOOP")
+    outs["default"] = run()
+    assert_close(outs["default"], ref, BF, what=f"wide kernel, default loop {case}")
+    for loop in ("2", "0", "1"):
+        assert torch.equal(outs["default"], outs[loop]), f"loop flavour {loop} differs from the default on {case}"

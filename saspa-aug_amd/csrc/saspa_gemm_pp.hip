@@ -28,6 +28,8 @@
 //     before the phase that first reads it.  Nothing is drained to vmcnt(0) inside the loop.
 //   * tail: tiles beyond the K range are "staged" with out-of-range offsets (the DMA writes zeros
 //     into slots nobody reads again), which keeps the per-wave vmcnt arithmetic uniform.
+//   * round 5: the default loop merges the phases in pairs (LOOP == 2 below: two 40-MFMA intervals per K-tile, the second
+//     slice's A fragments read inside the block); the four-phase loop described above is LOOP == 0, kept as an A/B arm.
 //   * epilogue (round 4): each wave group finishes its own 128-row half, 64 rows at a time -- bias / time-embedding rows
 //     from LDS slots filled by DMA at tile set-up, bf16 staging, LDS-only barrier, coalesced 16-byte store pass with the
 //     residual loads of a batch in flight together, GroupNorm statistics accumulated over both passes; split-K writes

@@ -1041,21 +1041,30 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
 
 int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn) {
   if (!saspa_gemm_pp_eligible(p)) return SASPA_ERANGE;
-  // K loop flavour (read per launch; all three are bit-identical: same MFMA order per accumulator):
+  // K loop flavour (read per launch; all are bit-identical: same MFMA order per accumulator):
   //   SASPA_GEMM_PP_LOOP=2 (default since round 5)  two-barrier ping-pong, TWO 40-MFMA intervals per K-tile: +2 ... +8 % on every
   //                         shape against =0 (tools/pp_ab.py, profiles/r5_pp_long_ab.txt)
   //   =0  two-barrier ping-pong, four 20-MFMA phases per K-tile (rounds 2 - 4)
-  //   =1  one barrier per phase, asymmetric programs (round 3: 12 - 30 % SLOWER, profiles/r3_pp_ab_v*.txt; A/B arm only)
+  //   =1  one barrier per phase, asymmetric programs (round 3: 12 - 30 % SLOWER, profiles/r3_pp_ab_v*.txt).  Only in the
+  //       diagnostics library (`make ABLATION=1`): its 340 bytes of scratch per lane are not something the shipped library should
+  //       ever ask the runtime for; the shipped library reads =1 as the default
   if (fn == 4 || fn == 5) {
     const char* e = getenv("SASPA_GEMM_PP_LOOP");
     const int loop = e ? atoi(e) : 2;
+#ifdef SASPA_GEMM_ABLATION
     if (loop == 1) fn += 10;
-    if (loop == 2) fn += 20;
+#endif
+    if (loop != 0 && loop != 1) fn += 20;
+#ifndef SASPA_GEMM_ABLATION
+    if (loop == 1) fn += 20;
+#endif
   }
   if (fn == 5) return launch_pp<5, 0>(p, s, ksplit);
   if (fn == 4) return launch_pp<4, 0>(p, s, ksplit);
+#ifdef SASPA_GEMM_ABLATION
   if (fn == 15) return launch_pp<5, 1>(p, s, ksplit);
   if (fn == 14) return launch_pp<4, 1>(p, s, ksplit);
+#endif
   if (fn == 25) return launch_pp<5, 2>(p, s, ksplit);
   if (fn == 24) return launch_pp<4, 2>(p, s, ksplit);
   return SASPA_ERANGE;

@@ -2,7 +2,8 @@
 ping-pong loop with four 20-MFMA phases per K-tile (SASPA_GEMM_PP_LOOP=0) against the one-barrier-per-phase asymmetric loop
 (=1, round 3) and the two-barrier loop with two 40-MFMA phases per K-tile (=2, round 5), on the conv / linear shapes the
 pipeline sends to that kernel; outputs must be bit-identical (same MFMA order per accumulator).
-usage: python tools/pp_ab.py [704] [arms=pingpong,long]"""
+usage: python tools/pp_ab.py [704] [arms=pingpong,long]     (the `asym` arm needs the diagnostics library: `make ABLATION=1`,
+SASPA_HIP_LIB=saspa-aug_amd/libsaspa_hip_abl.so -- the shipped library reads SASPA_GEMM_PP_LOOP=1 as the default loop)"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401

@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 # its N rank processes BEFORE anything in this (parent) process can touch the GPU.
 
 BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_SUSTAINED_TFLOPS = 2000.0        # measured, random operands, power-limited (profiles/r5_mfma_microbench.txt)
 F_IMG_50 = 109.33e12               # algorithmic FLOP / 512x512 image at 50 steps
 
 
@@ -452,6 +453,13 @@ def run(args):
                          "production step graph the two encoder branches run side by side with sharing = 1, i.e. the 32x32 / "
                          "16x16 levels take fewer K slices there than in this per-launch table (their reduce / splitk_gn launches "
                          "are timed here under their own kinds)")
+        # what the matrix pipe sustains on random bf16 data when it does nothing else (all 256 CUs, independent MFMAs from
+        # registers: the power limit holds the clock at 2.0 GHz; tools/micro/mfma_issue_bench.hip, round 5).  `peak` / `frac` above
+        # stay priced against the guide's 2.5 PFLOP/s
+        roof["peak_sustained_measured"] = dict(value=MFMA_SUSTAINED_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_SUSTAINED_TFLOPS, 4),
+                                               what="back-to-back v_mfma_f32_16x16x32_bf16 on pseudo-random operands, power-limited "
+                                                    "(2 390 - 2 450 on small-integer operands; 1 795 for v_mfma_f32_32x32x16_bf16)",
+                                               source="profiles/r5_mfma_microbench.txt")
         roof["algorithmic_bytes"] = round(gm["bytes"] / gm["launches"])
         roof["algorithmic_bytes_unit"] = ("operand bytes per launch (input pixels + weights + output + residual, each once, bf16), "
                                           "avg over the same launches as `achieved`")

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
         if (abl & 32) tloop0 = __builtin_amdgcn_s_memtime();
         auto qphase = [&](const int Q) __attribute__((always_inline)) {
           if (!(abl & 8)) __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_s_setprio(1);
+          if (!(abl & 64)) __builtin_amdgcn_s_setprio(1);          // (bit 64: A/B of the block's priority; no measurable effect)
           mma_row(0, 4 * Q + 0);
           __builtin_amdgcn_sched_barrier(0);
           if (!(abl & 2)) read_a2(0, 2 * Q + 1);
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
           __builtin_amdgcn_sched_barrier(0);
           mma_row(0, 4 * Q + 2);
           mma_row(1, 4 * Q + 3);
-          __builtin_amdgcn_s_setprio(0);
+          if (!(abl & 64)) __builtin_amdgcn_s_setprio(0);
           long long tb = 0;
           if (abl & 32) { __builtin_amdgcn_sched_barrier(0); tb = __builtin_amdgcn_s_memtime(); }
           if (!(abl & 8)) __builtin_amdgcn_s_barrier();

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "saspa-aug_amd", "csrc")
 TABLE = (("full", 0), ("no LDS reads", 2), ("no DMA", 4), ("no reads, no DMA (MFMA + barriers)", 6), ("no barriers", 8),
          ("MFMA only", 14), ("no MFMA", 1), ("barriers only", 7), ("stamps: wait behind an MFMA block (loop 2)", 32),
-         ("stamps, no DMA", 36), ("stamps, no reads", 34))
+         ("stamps, no DMA", 36), ("stamps, no reads", 34), ("no s_setprio around the MFMA block (loop 2)", 64),
+         ("stamps + no s_setprio", 96))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     objs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".o") and ".abl." not in f and not f.startswith("saspa_gemm_pp")]
     only = [int(a) for a in sys.argv[2:]]
@@ -49,7 +50,9 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
         wt.saspa_korder = 1
         o = torch.empty(b, h, w_, cout, device=dev, dtype=torch.bfloat16)
         out.append(timeit(lambda: ops.conv(x, wt, None, kh=3, kw=3, pad=1, variant=ops.GEMM_WIDE, out=o)))
-        if "_ct3" in os.environ.get("SASPA_HIP_LIB", "") and os.environ.get("SASPA_GEMM_PP_LOOP") == "2":
+        import re
+        m_ = re.search(r"_ct(\d+)\.so", os.environ.get("SASPA_HIP_LIB", ""))
+        if m_ and (int(m_.group(1)) & 32) and os.environ.get("SASPA_GEMM_PP_LOOP") == "2":
             torch.cuda.synchronize()
             d = o.view(-1)[:16].view(torch.int32).cpu().tolist()      # waves 0 / 4 of workgroup 0: {sum Q0, sum Q1, loop, intervals}
             for g in (0, 1):

@@ -155,7 +155,9 @@ typedef struct SaspaGemmParams {
   int sharing;
   /* ABI 18.  1: when the launch runs on K slices (ksplit > 1 with a workspace), saspa_gemm leaves the fp32 partial slabs in
    * `workspace` and does NOT run its reduce / epilogue launch -- the caller hands them to saspa_splitk_groupnorm, which sums
-   * them, adds bias / row vector and applies the consuming GroupNorm in the same launch (`out` is then not written). */
+   * them, adds bias / row vector and applies the consuming GroupNorm in the same launch (`out` is then not written).
+   * ABI 19: a contract, not a hint -- a launch that would end on ONE K slice or on a kernel without slabs (fused GEGLU, N <= 32,
+   * the weight-stationary and A-stationary kernels) returns SASPA_ERANGE instead of writing `out` behind the caller's back. */
   int defer_reduce;
 } SaspaGemmParams;
 /* Non-zero if the A-stationary kernel can run the problem (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at least 192

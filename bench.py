@@ -497,6 +497,7 @@ def run(args):
         if f_img:
             roof["pipeline_tflops_per_gpu"] = round(value / n_gpus * f_img / 1e12, 1)
             roof["pipeline_frac_of_peak"] = round(value / n_gpus * f_img / 1e12 / BF16_PEAK_TFLOPS, 4)
+            roof["pipeline_frac_of_sustained_measured"] = round(value / n_gpus * f_img / 1e12 / MFMA_SUSTAINED_TFLOPS, 4)
 
     cpu = None
     extra = None

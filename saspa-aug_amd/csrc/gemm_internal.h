@@ -1,5 +1,6 @@
 // Internal (not exported) entry points shared between the GEMM translation units.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "saspa_hip.h"
@@ -12,6 +13,21 @@ __attribute__((visibility("hidden"))) bool saspa_gemm_pp_eligible(const SaspaGem
 __attribute__((visibility("hidden"))) int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit);
 // N-partitioned tile order (weight-heavy problems): nbn / 8 if the launch should use it, else 0 (saspa_gemm.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_npart8(const SaspaGemmParams& p, int BM, int BN, int G, int tiles);
+// Persistent grid of a one-workgroup-per-CU kernel (round 5): `tiles` work items over at most `cap` workgroups.  With tiles just above
+// a whole number of rounds (352 row tiles of the 64x88 level at 512x704: 1.375 rounds) a grid of `cap` workgroups makes a few of
+// them run one tile more than the rest while the others idle -- and every tile pays the contention of a full chip.  A grid of
+// ceil(tiles / rounds) workgroups gives every workgroup the SAME number of tiles on fewer CUs: 176 workgroups x 2 tiles run the
+// level-0 conv of that bucket in 149 us against 174 (tools/msplit_704.py: fewer CUs store at once and the power limit leaves them
+// a higher clock).  SASPA_GEMM_BALANCE=0 = the old rule (A/B).
+static inline int saspa_balanced_grid(int tiles, int cap) {
+  if (cap < 1) cap = 1;
+  if (tiles <= cap) return tiles;
+  static const bool off = getenv("SASPA_GEMM_BALANCE") && atoi(getenv("SASPA_GEMM_BALANCE")) == 0;
+  if (off) return cap;
+  const int rounds = (tiles + cap - 1) / cap;
+  return (tiles + rounds - 1) / rounds;
+}
+
 // wave-specialised 8-wave kernel for short-K bf16 layers (saspa_gemm_ws.hip)
 __attribute__((visibility("hidden"))) int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s);
 __attribute__((visibility("hidden"))) bool saspa_gemm_ws_eligible(const SaspaGemmParams& p);

@@ -802,8 +802,7 @@ extern "C" int saspa_conv3x3_halo(const SaspaGemmParams* pp, const SaspaConvGnPa
   ks = (geo.nper + geo.per_slice - 1) / geo.per_slice;           // no empty slices: the reduce sums exactly `ks` slabs
   geo.gn_slabs = gp ? saspa_gn_slabs((p.c0 + p.c1) / 8) : 1;
   geo.ntiles = tiles;
-  int gx = tiles;
-  if ((long long)tiles * ks > 256) gx = max(1, min(tiles, 256 / ks));
+  const int gx = saspa_balanced_grid(tiles, 256 / ks);
   dim3 grid(gx, ks, 1);
   SaspaConvGnParams g0 = {};
   const SaspaConvGnParams& g = gp ? *gp : g0;

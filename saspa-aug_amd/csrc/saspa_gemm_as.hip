@@ -101,7 +101,21 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  const long long row = (long long)blockIdx.x * AS_BM + wave * 32 + m;
+  // ---- work partition (round 5): the (row block, column slice) steps of the whole problem, block-major, are dealt to the
+  // workgroups in CONTIGUOUS shares of ceil(total / grid) steps.  A share that starts or ends inside a row block is a "run" of
+  // that block's slices: slices are independent outputs, so nothing has to be combined.  With 256 row blocks (512x512) every
+  // workgroup gets exactly one whole block -- the launch of rounds 3 - 4; with 352 (512x704: 1.375 rounds, which used to
+  // disqualify the kernel) every workgroup gets 1.375 blocks' worth in two or three runs, each reloading its rows.
+  const int nslices_all = p.N / AS_BN;
+  const long long total_steps = (long long)((p.M + AS_BM - 1) / AS_BM) * nslices_all;
+  const long long share = (total_steps + gridDim.x - 1) / gridDim.x;
+  long long pos = (long long)blockIdx.x * share;
+  const long long pend = pos + share < total_steps ? pos + share : total_steps;
+  while (pos < pend) {
+  const int blk = (int)(pos / nslices_all);
+  const int s_first = (int)(pos - (long long)blk * nslices_all);
+  const int nslices = (int)((pend - pos) < (long long)(nslices_all - s_first) ? (pend - pos) : (long long)(nslices_all - s_first));   // slices of this run
+  const long long row = (long long)blk * AS_BM + wave * 32 + m;
   const bool live = row < p.M;
 
   // ---- this lane's half of row `row`: channels 16 s + 8 h .. + 8, s = 0 .. 19 ----
@@ -115,14 +129,14 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   const rsrc_t rsw = make_rsrc(p.w);
   const rsrc_t rsb = make_rsrc(p.bias);
   const bool has_bias = p.bias != nullptr;
-  const int nslices = p.N / AS_BN;
-  // Every workgroup walks the slices in a rotated order (its own starting slice; workgroups of one XCD -- blockIdx = xcd + 8 k --
-  // get consecutive starts), so that the 256 workgroups do not all ask the L2 for the same 40 KB in the same microsecond.
-  // (Measured neutral on its own -- the DMA alone runs at 10.8 TB/s either way, tools/as_ablate.py -- kept: it costs nothing.)
-  const int rot = (int)((blockIdx.x >> 3) % (unsigned)nslices);
-  auto slice_of = [&](int i) __attribute__((always_inline)) -> int {      // i-th slice this workgroup processes
+  // A run that covers its whole block walks the slices in a rotated order (its own starting slice; workgroups of one XCD --
+  // blockIdx = xcd + 8 k -- get consecutive starts), so that the 256 workgroups do not all ask the L2 for the same 40 KB in the
+  // same microsecond.  (Measured neutral on its own -- the DMA alone runs at 10.8 TB/s either way, tools/as_ablate.py -- kept:
+  // it costs nothing.)  Partial runs start where their share starts, which staggers them by itself.
+  const int rot = nslices == nslices_all ? (int)((blockIdx.x >> 3) % (unsigned)nslices) : 0;
+  auto slice_of = [&](int i) __attribute__((always_inline)) -> int {      // i-th slice of this run
     const int u = i + rot;
-    return u >= nslices ? u - nslices : u;
+    return s_first + (u >= nslices ? u - nslices : u);
   };
   int dn[AS_NDMA], dkc[AS_NDMA];
 #pragma unroll
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
   // store layout of the staged tile: instruction i covers rows RPI * i + lane / LPR, 16-byte chunk lane % LPR of the row
   constexpr int LPR = EPI == 1 ? 4 : 8, RPI = 64 / LPR, NST = 32 / RPI, SPITCH = EPI == 1 ? 72 : AS_STG_PITCH;
   unsigned char* stg = reinterpret_cast<unsigned char*>(lds + AS_RING * AS_STAGE) + wave * AS_STG_WAVE;
-  const long long row0 = (long long)blockIdx.x * AS_BM + wave * 32;
+  const long long row0 = (long long)blk * AS_BM + wave * 32;
   unsigned so_off[NST], sr_off[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
@@ -428,6 +442,14 @@ __global__ __launch_bounds__(512, 1) void gemm_as_kernel(const SaspaGemmParams p
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) epilogue_part(gi, tl, done, rv);
   }
+  pos += nslices;
+  if (pos < pend) {
+    // another run follows: its DMA reuses the ring, its epilogue the staging tile and the bias slots -- drain this run's
+    // vector-memory operations (tail DMAs of slices past the end write zeros into the ring) and let every wave finish reading
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  }   // runs of this workgroup
 #ifdef SASPA_AS_STAMPS
   if (stamping)
     for (int i = 0; i < 160; ++i) (reinterpret_cast<unsigned long long*>(p.workspace) + (threadIdx.x ? 4096 : 0))[i] = stamps[i];
@@ -464,7 +486,13 @@ bool saspa_gemm_as_ok(const SaspaGemmParams& p) {
 
 int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s) {
   if (!saspa_gemm_as_ok(p)) return SASPA_ERANGE;
-  const dim3 grid((p.M + AS_BM - 1) / AS_BM);
+  // one workgroup per CU, the steps dealt evenly (see the kernel); SASPA_GEMM_BALANCE=0: one workgroup per row block as before
+  const long long nblk = (p.M + AS_BM - 1) / AS_BM, steps = nblk * (p.N / AS_BN);
+  static const bool balance_off = getenv("SASPA_GEMM_BALANCE") && atoi(getenv("SASPA_GEMM_BALANCE")) == 0;
+  // few slices per block (N = 320: five): a share of 6.9 steps would reload and re-normalise its rows twice for seven slices
+  // -- measured slower than letting the hardware deal whole blocks (LayerNorm + N = 320 at 352 blocks: 60 us against 53.5)
+  const bool whole_blocks = balance_off || p.N / AS_BN < 8 || nblk % 256 == 0;
+  const dim3 grid((unsigned)(whole_blocks ? nblk : (steps < 256 ? steps : 256)));
   const int abl = 0;
   if (p.act == SASPA_ACT_GEGLU) {
     if (p.N % 160 == 0) hipLaunchKernelGGL((gemm_as_kernel<1, false, 160>), grid, dim3(512), 0, s, p, abl);
@@ -478,10 +506,14 @@ int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s) {
   return 0;
 }
 
-// 0: cannot run; 1: can; 2: can, and the row blocks fill whole rounds of the 256 CUs (>= 85 % of the last round) -- the sizes
-// where the kernel beats the wave-specialised one on the GEGLU projection too (tools/as_bench.py; 352 blocks at 512x704 do not)
+// 0: cannot run; 1: can; 2: can, and the work fills the chip evenly -- the sizes where the kernel beats the wave-specialised one
+// on the GEGLU projection too (tools/as_bench.py).  Until round 5 that meant row blocks filling whole rounds of the 256 CUs
+// (>= 85 % of the last round: 352 blocks at 512x704 did not); with the steps dealt evenly every eligible size does.
+// SASPA_GEMM_BALANCE=0 restores the old launch and the old answer.
 extern "C" int saspa_gemm_as_eligible(const SaspaGemmParams* p) {
   if (!p || !saspa_gemm_as_ok(*p)) return 0;
+  static const bool balance_off = getenv("SASPA_GEMM_BALANCE") && atoi(getenv("SASPA_GEMM_BALANCE")) == 0;
+  if (!balance_off) return 2;
   const long long blocks = (p->M + AS_BM - 1) / AS_BM;
   return blocks * 100 >= ((blocks + 255) / 256) * 256 * 85 ? 2 : 1;
 }

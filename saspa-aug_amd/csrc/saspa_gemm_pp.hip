@@ -999,8 +999,7 @@ int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 256, BN = 64 * FN;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int zy = ksplit * p.nb1 * p.nb2;
-  int gx = tiles;
-  if ((long long)tiles * zy > 256) gx = max(1, min(tiles, 256 / zy));
+  const int gx = saspa_balanced_grid(tiles, 256 / zy);
   dim3 grid(gx, ksplit, p.nb1 * p.nb2);
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;
   static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;   // diagnostics only

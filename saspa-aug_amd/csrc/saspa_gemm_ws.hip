@@ -465,7 +465,7 @@ int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s) {
   const bool n160 = (p.N % 160) == 0;
   const int bn = n160 ? 160 : 128;
   const int tiles = ((p.N + bn - 1) / bn) * ((p.M + 127) / 128);
-  const int gx = tiles < 256 ? tiles : 256;
+  const int gx = saspa_balanced_grid(tiles, 256);
   static const int abl = getenv("SASPA_GEMM_ABLATE") ? (atoi(getenv("SASPA_GEMM_ABLATE")) & 15) : 0;   // diagnostics only (8 = stamps)
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0;
   const bool gg = p.act == SASPA_ACT_GEGLU;

@@ -33,7 +33,9 @@ def _ref(x, w, b, res=None):
     return r
 
 
-@pytest.mark.parametrize("m,n", [(49152, 320), (49152, 640), (49152 + 200, 320), (90112, 64)])
+# 90 112 rows = 352 row blocks (512x704): since round 5 the steps are dealt evenly, a workgroup runs 1.375 blocks' worth in two or
+# three runs; 49 152 = 192 blocks: three quarters of a block each
+@pytest.mark.parametrize("m,n", [(49152, 320), (49152, 640), (49152 + 200, 320), (90112, 64), (90112, 320), (90112 + 72, 960)])
 @pytest.mark.parametrize("bias,residual", [(True, False), (False, False), (True, True)])
 def test_plain(dev, m, n, bias, residual):
     x, w, b = _mk(m, n, m + n, dev, bias)
@@ -67,7 +69,7 @@ def test_not_eligible_falls_back_or_refuses(dev):
         ops.linear(x, w, b, ln=(g, be, 1e-5))               # a fused LayerNorm needs the kernel
 
 
-@pytest.mark.parametrize("m,n", [(49152, 2560), (65536, 1280), (49152, 1024)])      # 1024: the 128-column GEGLU packing
+@pytest.mark.parametrize("m,n", [(49152, 2560), (65536, 1280), (49152, 1024), (90112, 2560)])      # 1024: the 128-column GEGLU packing
 def test_geglu(dev, m, n):
     g = torch.Generator().manual_seed(n)
     x = torch.randn(m, K, generator=g).to(dev, BF)
@@ -88,7 +90,7 @@ def test_geglu(dev, m, n):
     assert (got.double().cpu() - ref).abs().mean().item() <= (tiled.double().cpu() - ref).abs().mean().item() * 1.01
 
 
-@pytest.mark.parametrize("m,n", [(49152, 320), (65536, 2560)])
+@pytest.mark.parametrize("m,n", [(49152, 320), (65536, 2560), (90112, 2560), (98304, 320)])
 def test_fused_layernorm(dev, m, n):
     act = ops.ACT_GEGLU if n == 2560 else ops.ACT_NONE
     g = torch.Generator().manual_seed(7)
@@ -107,11 +109,11 @@ def test_fused_layernorm(dev, m, n):
     assert d.max().item() <= 2 ** -6 * scale and (d > 0).float().mean().item() < 2e-2, (d.max().item(), (d > 0).float().mean().item())
 
 
-def test_qkv_one_launch(dev):
+@pytest.mark.parametrize("b,ntok", [(12, 4096), (16, 5632)])      # 5632 tokens: the 64x88 level of 512x704 (352 row blocks)
+def test_qkv_one_launch(dev, b, ntok):
     """[to_q; to_k; to_v] (960 x 320) with a fused LayerNorm: Q | K row-major, V^T per sample -- against LayerNorm + the two
     launches of the tiled path (models.project_vt)."""
     from saspa_aug_amd import models
-    b, ntok = 12, 4096
     g = torch.Generator().manual_seed(11)
     h = torch.randn(b, ntok, K, generator=g).to(dev, BF)
     gamma, beta = (1 + 0.3 * torch.randn(K, generator=g)).to(dev), (0.2 * torch.randn(K, generator=g)).to(dev)
@@ -131,11 +133,12 @@ def test_qkv_one_launch(dev):
 
 
 def test_eligibility_levels(dev):
-    """saspa_gemm_as_eligible: 0 = cannot, 1 = can but the last round of row blocks is ragged, 2 = whole rounds."""
+    """saspa_gemm_as_eligible: 0 = cannot, 2 = can and fills the chip (since round 5 the steps are dealt evenly, so every
+    eligible size does; 1 = "can, ragged last round" is only returned with SASPA_GEMM_BALANCE=0)."""
     w = torch.zeros(320, K, device=dev, dtype=BF)
     mk = lambda m: torch.zeros(m, K, device=dev, dtype=BF)
     assert ops.linear_ln_fusable(mk(65536), w) == 2            # 256 blocks: one whole round
-    assert ops.linear_ln_fusable(mk(90112), w) == 1            # 352 blocks: 512x704
+    assert ops.linear_ln_fusable(mk(90112), w) == 2            # 352 blocks: 512x704
     assert ops.linear_ln_fusable(mk(131072), w) == 2           # 512 blocks
     assert ops.linear_ln_fusable(mk(16384), w) == 0            # 64 blocks: cannot fill the chip
     assert ops.linear_ln_fusable(mk(65536).float(), w) == 0    # bf16 only

@@ -75,3 +75,40 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _release_gpu_state_between_modules():
+    """After every test module: collect dead pipelines (their captured step graphs and the graphs' private memory pools are only
+    released when the objects go) and hand the cached device memory back.  A full `-m gpu` session builds ~40 pipelines; twice
+    in round 5 a session that had just gained a few tests ended in a segmentation fault inside hipGraphLaunch at the SAME later
+    test (the first fp32 pipeline of test_models_gpu.py), which passes alone and in a session without those tests: a runtime
+    resource that a long session exhausts, not that test."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
+
+
+# Two-branch step graphs (SASPA_FORK, default on in the product) in a LONG multi-pipeline session: four of the five full `-m gpu`
+# sessions of round 5 ended in a segmentation fault inside the HIP runtime -- hip::GraphExec::Run -> hip::Graph::UpdateStreams
+# (rocgdb backtrace, profiles/EXPERIMENTS.md) -- at the replay of a tiny fp32 pipeline's graph ~490 tests in; each such test
+# passes alone, 300 live two-branch graphs in one process do not reproduce it (tools/graph_leak_probe.py), and the same session
+# with single-branch graphs passes.  The production path (one pipeline per process) has never shown it.  So: the two-branch form
+# stays on where it is what is being tested or measured (the production-size modules, which run first, and the graph tests);
+# every other module captures single-branch graphs.  A test that sets SASPA_FORK itself (monkeypatch) overrides this.
+_FORK_MODULES = ("test_production_gpu.py", "test_production_families_gpu.py", "test_graph_gpu.py", "test_config3_gpu.py")
+
+
+@pytest.fixture(autouse=True)
+def _single_branch_graphs_outside_the_graph_tests(request, monkeypatch):
+    if request.node.fspath.basename not in _FORK_MODULES and "SASPA_FORK" not in os.environ:
+        monkeypatch.setenv("SASPA_FORK", "0")
+    yield

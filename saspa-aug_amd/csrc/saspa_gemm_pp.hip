@@ -558,9 +558,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const SaspaGemmParams p, c
 #endif
       } else if (LOOP == 2) {
         // ---- long ping-pong (round 5): the loop below with its phases merged in pairs ----
-        // What the two-barrier hand-off costs does not depend on the length of the MFMA block it separates (measured: 424
-        // cycles per interval for MFMAs + barriers against 320 of MFMA, DESIGN 7 / EXPERIMENTS), so a K-tile is cut into TWO
-        // intervals of 40 MFMAs (Q0: slices 0, 1; Q1: slices 2, 3) instead of four of 20.  No more fragment registers than
+        // Fewer, longer intervals: a K-tile is cut into TWO intervals of 40 MFMAs (Q0: slices 0, 1; Q1: slices 2, 3) instead
+        // of four of 20.  (Built on the rounds 3 - 4 reading that a hand-off costs ~100 cycles; measured properly this round it is
+        // ~12 -- tools/micro/barrier_bench.hip -- and what the merge really buys is fewer per-interval waits on the partner's DMA
+        // issue: +2 ... +8 % per launch, profiles/r5_pp_long_ab.txt.)  No more fragment registers than
         // before: the MFMAs of a slice run row-fragment-major (i outer), and the A fragments of the interval's SECOND slice are
         // read inside the block into the registers its first slice has just released (10 MFMAs = 160 cycles of cover each).
         // Per accumulator the K order is unchanged (kk = 0, then 1): bit-identical to the other loops.

@@ -1000,6 +1000,8 @@ int launch_pp(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 256, BN = 64 * FN;
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   const int zy = ksplit * p.nb1 * p.nb2;
+  // (balancing the launches of the paired encoders for HALF the chip -- cap 128 under SaspaGemmParams.sharing -- measured
+  // 0 / -1.2 / 0 % at 512x512 / 512x704 / 512x768: the dispatcher's own interleaving of the two queues does better)
   const int gx = saspa_balanced_grid(tiles, 256 / zy);
   dim3 grid(gx, ksplit, p.nb1 * p.nb2);
   const bool pw = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.upsample;

@@ -185,3 +185,17 @@ def test_wide_loop_flavours_bit_identical(dev, monkeypatch, case):
     assert_close(outs["default"], ref, BF, what=f"wide kernel, default loop {case}")
     for loop in ("2", "0"):
         assert torch.equal(outs["default"], outs[loop]), f"loop flavour {loop} differs from the default on {case}"
+
+
+@pytest.mark.parametrize("b,h,w_", [(16, 64, 88), (12, 64, 96), (9, 64, 64)])
+def test_wide_conv_tile_counts_just_above_a_round(dev, b, h, w_):
+    """352 / 288 / 144 row tiles of 256: since round 5 a tile count just above a whole number of rounds of the 256 CUs launches
+    ceil(tiles / rounds) workgroups, every one walking the same number of tiles (64x88 is the level-0 size of the 512x704 bucket)."""
+    cin, cout = 64, 320
+    x = q(_rand(b, cin, h, w_, seed=61), BF)
+    wt = q(_rand(cout, cin, 3, 3, seed=62, scale=1 / math.sqrt(9 * cin)), BF)
+    bias, rv = _rand(cout, seed=63), _rand(b, cout, seed=64)
+    ref = F.conv2d(x, wt, bias, padding=1) + rv[:, :, None, None]
+    out = ops.conv(to_nhwc(x, BF, dev), W.pack_conv(wt).to(dev, BF), bias.to(dev), kh=3, kw=3, pad=1, rowvec=rv.to(dev),
+                   variant=ops.GEMM_WIDE, ksplit=1)
+    assert_close(from_nhwc(out, cout), ref, BF, what=f"wide conv, {b * h * w_ // 256} row tiles")

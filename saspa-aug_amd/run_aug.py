@@ -415,25 +415,38 @@ def default_prompts_file(s: Settings):
     return str(here / "gpt_prompts" / f"{name}-100-gpt_v1.txt")
 
 
-def _png_orientation(path):
+def _png_orientation(path, im=None):
     """EXIF orientation of a PNG without decoding it: the eXIf chunk may sit before or after the IDAT chunks, so the chunk
-    headers are walked (8 bytes each, data skipped by seek) up to IEND.  1 when there is none."""
+    headers are walked (8 bytes each, data skipped by seek) up to IEND.  1 when there is none.
+    Pillow's `getexif()` -- what `ImageOps.exif_transpose` in `load_raw` consults -- also takes the orientation from a
+    `Raw profile type exif` tEXt / zTXt chunk (ImageMagick-written PNGs) and from an XMP packet's `tiff:Orientation`
+    (iTXt): a PNG that has no eXIf chunk but carries ANY text chunk is therefore handed to Pillow itself (`im`, or the
+    file re-opened), so that the plan and the loader can never disagree; the fast path stays for PNGs with neither."""
     import struct
+    text_chunk = False
     with open(path, "rb") as f:
         if f.read(8) != b"\x89PNG\r\n\x1a\n":
             return 1
         while True:
             head = f.read(8)
             if len(head) < 8:
-                return 1
+                break
             n, kind = struct.unpack(">I4s", head)
             if kind == b"eXIf":
                 ex = Image.Exif()
                 ex.load(f.read(n))
                 return ex.get(0x0112, 1)
+            if kind in (b"tEXt", b"zTXt", b"iTXt"):
+                text_chunk = True
             if kind == b"IEND":
-                return 1
+                break
             f.seek(n + 4, 1)
+    if not text_chunk:
+        return 1
+    if im is not None:
+        return im.getexif().get(0x0112, 1)
+    with Image.open(path) as im2:
+        return im2.getexif().get(0x0112, 1)
 
 
 def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_classes_dict, image_size_fn=None,
@@ -448,7 +461,7 @@ def plan_work(s: Settings, original_images_paths, prompts, output_folder, image_
                 w, h = im.size
                 # PNG: Pillow's getexif() DECODES the picture to reach an eXIf chunk behind the pixel data (20 ms per
                 # 1024 x 683 source: 69 s of a 3 334-image plan, tools/config3_rehearsal.py); walk the chunk headers instead
-                orientation = _png_orientation(path) if im.format == "PNG" else im.getexif().get(0x0112, 1)
+                orientation = _png_orientation(path, im) if im.format == "PNG" else im.getexif().get(0x0112, 1)
                 if orientation in (5, 6, 7, 8):
                     w, h = h, w
             th, tw, _ = utils.resize_target_size(h, w, s.RESOLUTION)

@@ -62,6 +62,55 @@ def test_plan_uses_the_exif_transposed_size(tmp_path):
     assert (items[0].height, items[0].width) == loaded.shape[:2]
 
 
+def _png_with_text_orientation(path, kind):
+    """A 128x64 PNG that carries EXIF orientation 6 WITHOUT an eXIf chunk: as ImageMagick's `Raw profile type exif` text chunk
+    (hex dump of the EXIF blob) or as an XMP packet's tiff:Orientation (iTXt) -- both are sources Pillow's getexif() reads."""
+    from PIL import PngImagePlugin
+    img = Image.fromarray(np.random.RandomState(0).randint(0, 255, (64, 128, 3), np.uint8))
+    info = PngImagePlugin.PngInfo()
+    if kind == "raw_profile":
+        exif = Image.Exif()
+        exif[0x0112] = 6
+        raw = exif.tobytes()
+        blob = raw if raw.startswith(b"Exif\x00\x00") else b"Exif\x00\x00" + raw
+        hexed = blob.hex()
+        body = "\nexif\n%8d\n" % len(blob) + "\n".join(hexed[i:i + 72] for i in range(0, len(hexed), 72)) + "\n"
+        info.add_text("Raw profile type exif", body, zip=(kind == "raw_profile"))
+    else:
+        xmp = ('<?xpacket begin="" id="W5M0MpCehiHzreSzNTczkc9d"?><x:xmpmeta xmlns:x="adobe:ns:meta/"><rdf:RDF '
+               'xmlns:rdf="http://www.w3.org/1999/02/22-rdf-syntax-ns#"><rdf:Description rdf:about="" '
+               'xmlns:tiff="http://ns.adobe.com/tiff/1.0/" tiff:Orientation="6"/></rdf:RDF></x:xmpmeta><?xpacket end="w"?>')
+        info.add_itxt("XML:com.adobe.xmp", xmp)
+    img.save(path, pnginfo=info)
+
+
+@pytest.mark.parametrize("kind", ["raw_profile", "xmp"])
+def test_plan_follows_pillow_for_png_orientation_outside_exif_chunks(tmp_path, kind):
+    """`_png_orientation` used to read the eXIf chunk only, while `load_raw` transposes by whatever
+    `Image.getexif()` finds (also a `Raw profile type exif` text chunk and XMP tiff:Orientation).  Whatever Pillow decides for
+    such a PNG -- transposed or not, that is version-dependent -- the planned (h, w) must be the loaded image's."""
+    p = tmp_path / f"rot_{kind}.png"
+    _png_with_text_orientation(p, kind)
+    with Image.open(p) as im:
+        pillow_says = im.getexif().get(0x0112, 1)
+    assert R._png_orientation(str(p)) == pillow_says
+    s = R.Settings(DATASET="synthetic", NUM_PER_IMAGE=1, RESOLUTION=64, USE_ARTISTIC_PROMPTS=False, PROMPT_WITH_SUB_CLASS=False)
+    np.random.seed(1)
+    items = R.plan_work(s, [str(p)], ["a photo of an airplane"], str(tmp_path / "out"), {})
+    loaded = R.load_source(str(p), 64)
+    assert (items[0].height, items[0].width) == loaded.shape[:2]
+    if pillow_says == 6:
+        assert loaded.shape[:2] == (128, 64)
+
+
+def test_png_orientation_fast_path_never_opens_pillow_exif(tmp_path, monkeypatch):
+    """A PNG with neither an eXIf nor a text chunk stays on the header walk (no decode: the 69 s -> 0.8 s of the configs[3] plan)."""
+    p = tmp_path / "plain.png"
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(p)
+    monkeypatch.setattr(Image.Image, "getexif", lambda self: (_ for _ in ()).throw(AssertionError("getexif called")))
+    assert R._png_orientation(str(p)) == 1
+
+
 def _synthetic_clip_vocab(tmp_path):
     b2u = _bytes_to_unicode()
     chars = [b2u[b] for b in range(256)]

@@ -91,6 +91,53 @@ class Recorder:
         return out
 
 
+class ClockSampler:
+    """Effective shader clock of the timed region: a host thread launches `ops.clock_probe` (ONE sleeping wave, ~1 ms window:
+    s_memtime shader clocks against the constant 100 MHz s_memrealtime) on its own stream every `period` seconds while the hot
+    path runs on the main stream.  Box-to-box spread of MFMA-dense loops is up to 12 % (MI355X_MICROARCH.md); with this the
+    record of a run says which clock the box granted it."""
+
+    def __init__(self, dev, period=0.1, max_samples=4096):
+        import threading
+
+        import torch
+        self.dev, self.period, self.n = dev, period, 0
+        self.buf = torch.zeros((max_samples, 2), dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import torch
+
+        from saspa_aug_amd import ops
+        torch.cuda.set_device(self.dev)
+        with torch.cuda.stream(self.stream):
+            while not self._stop.is_set() and self.n < self.buf.shape[0]:
+                ops.clock_probe(self.buf[self.n], 250)
+                self.n += 1
+                self._stop.wait(self.period)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        import torch
+        self._stop.set()
+        self._thread.join()
+        self.stream.synchronize()
+        v = self.buf[:self.n].cpu().double()
+        v = v[v[:, 1] > 0]
+        if v.shape[0] == 0:
+            return None
+        mhz = 100.0 * v[:, 0] / v[:, 1]
+        q = torch.quantile(mhz, torch.tensor([0.05, 0.5, 0.95], dtype=torch.float64))
+        return dict(sclk_mhz_mean=round(float(mhz.mean()), 1), sclk_mhz_p05=round(float(q[0]), 1), sclk_mhz_median=round(float(q[1]), 1),
+                    sclk_mhz_p95=round(float(q[2]), 1), samples=int(v.shape[0]), window_ms=round(float(v[:, 1].mean()) / 1e5, 3),
+                    how="one sleeping wave per sample on a side stream during the timed region: s_memtime / s_memrealtime (100 MHz)")
+
+
 def effective_cpus():
     """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -402,6 +449,7 @@ def run(args):
         torch.cuda.synchronize()
 
     barrier()
+    sampler = ClockSampler(dev).start() if rank == 0 else None
     t0 = time.time()
     status = []
     for i in range(args.steps):
@@ -414,6 +462,7 @@ def run(args):
         dist.gather(st, gathered, dst=0)
     barrier()
     dt = time.time() - t0
+    clock = sampler.stop() if sampler is not None else None
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -519,7 +568,7 @@ def run(args):
                        "batch_per_gpu": b, "resolution": res, "ddim_steps": s, "weights": "random-init, architecture-exact",
                        "parallelism": f"dp{n_gpus} (image shards, one RCCL gather of the status vector)",
                        "process_group": (f"nccl (RCCL), world {world}" if dist is not None else "none (single process)")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "clock": clock,
         }
         if extra is not None:
             line["baselines_full"] = extra

@@ -492,6 +492,14 @@ typedef struct SaspaXattnBlockParams {
 } SaspaXattnBlockParams;
 int saspa_xattn_block(const SaspaXattnBlockParams* p, void* stream);
 
+/* ---- measurement aid (ABI 20): effective shader clock under load ------------------------------------------------------
+ * One sleeping wave measures s_memtime (shader clocks) against s_memrealtime (constant 100 MHz) over iters x s_sleep 127
+ * (about 4 us each at 2 GHz; 1 <= iters <= 100000) and writes out2[0] = shader clocks, out2[1] = 100 MHz ticks:
+ * clock [MHz] = 100 * out2[0] / out2[1].  bench.py launches it on a side stream while the timed region runs, so that the
+ * record of a run carries the clock the box's power management granted it (MI355X_MICROARCH.md: MFMA-dense loops are
+ * power-limited and boxes differ by up to 12 %).  No counterpart in the reference (it reports no clocks). */
+int saspa_clock_probe(unsigned long long* out2, int iters, void* stream);
+
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);
 

@@ -103,6 +103,7 @@ SYMBOLS = {
     "saspa_gather_row_f32": (_I, [_P, _LL, _P, _P, _LL, _P]),
     "saspa_ddim_step_dev": (_I, [_I, _P, _P, _I, _LL, _I, _I, _I, _F, _P, _P, _P]),
     "saspa_index_add": (_I, [_P, _I, _P]),
+    "saspa_clock_probe": (_I, [_P, _I, _P]),
     "saspa_cfg_plms_step_dev": (_I, [_I, _P, _P, _P, _P, _I, _LL, _I, _I, _F, _P, _P, _P]),
     "saspa_scale": (_I, [_I, _P, _P, _LL, _F, _P]),
     "saspa_u8_to_act": (_I, [_I, _P, _P, _LL, _P]),

@@ -453,7 +453,27 @@ __global__ __launch_bounds__(256) void gather_row_kernel(const float* __restrict
 __global__ void index_add_kernel(int* index, int delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *index += delta;
 }
+// One sleeping wave: shader-clock cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over a window of
+// `iters` x s_sleep 127 (64 x 127 shader clocks each).  Launched on a side stream WHILE the hot path runs, it reads the
+// clock the power management grants the loaded chip; a sleeping wave issues nothing and holds 1 wave slot of one SIMD.
+__global__ void clock_probe_kernel(unsigned long long* out, int iters) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+}
 }  // namespace
+
+extern "C" int saspa_clock_probe(unsigned long long* out2, int iters, void* stream) {
+  if (!out2) return SASPA_EINVAL;
+  if (iters <= 0 || iters > 100000) return SASPA_ERANGE;          // <= ~0.4 s at 2 GHz: a probe always terminates
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out2, iters);
+  SASPA_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int saspa_gather_row_f32(const float* table, long long row_elems, const int* index, float* dst, long long n,
                                     void* stream) {
@@ -571,5 +591,5 @@ extern "C" int saspa_act_to_u8(int dtype, const void* x, int ldx, uint8_t* dst, 
   return 0;
 }
 
-extern "C" int saspa_abi_version(void) { return 19; }
+extern "C" int saspa_abi_version(void) { return 20; }
 extern "C" const char* saspa_build_arch(void) { return "gfx950"; }

@@ -920,6 +920,16 @@ def index_add(index, delta=1):
     return index
 
 
+def clock_probe(out2, iters=250):
+    """out2: int64 device tensor [2] <- (shader clocks, 100 MHz ticks) of a window of iters x s_sleep 127 (~1 ms at 250),
+    measured by one sleeping wave on the current stream (bench.py: a side stream, while the hot path runs)."""
+    _check_dev(out2)
+    if out2.dtype != torch.int64 or out2.numel() < 2 or not out2.is_contiguous():
+        raise ValueError("clock_probe wants a contiguous int64 tensor of >= 2 elements")
+    _lib.check(_lib.load().saspa_clock_probe(_ptr(out2), int(iters), _stream()), "saspa_clock_probe")
+    return out2
+
+
 def vae_sample_noise(moments, e1, e2, scaling, sa, s1m):
     """moments [B,h,w,8] (mean | logvar), e1 / e2 [B,h,w,8] noise draws -> noised start latents [B,h,w,8] (img2img)."""
     _check_dev(moments, e1, e2)

@@ -46,6 +46,24 @@ def fork_enabled():
     return os.environ.get("SASPA_FORK", "1") != "0"
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """THE second capture stream of a device: one per process and device, shared by every step graph (round 6).  Each
+    _StepGraph used to take its own stream out of torch's 32-stream pool; a long session that captured two-branch graphs for
+    dozens of pipelines ended in a segmentation fault inside hipGraphLaunch (hip::Graph::UpdateStreams,
+    profiles/r5_graph_replay_segv_backtrace.txt).  SASPA_SIDE_STREAM=per_graph restores the old behaviour for A/B."""
+    if os.environ.get("SASPA_SIDE_STREAM", "shared") == "per_graph":
+        return torch.cuda.Stream(device=device)
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _StepGraph:
     """ONE captured hipGraph of a sampling step -- UNet encoder, ControlNet, UNet decoder, (CFG +) DDIM or PLMS update,
     ~1 500 kernel nodes -- replayed once per network evaluation.  Launching those kernels from Python costs 1.28 s per batch-8 / 50-step
@@ -135,7 +153,7 @@ class _StepGraph:
             # changes is that one branch's launch gaps / tile tails / small deep-level kernels are filled by the other's work.
             main = torch.cuda.current_stream()
             if self.side is None:
-                self.side = torch.cuda.Stream(device=x.device)
+                self.side = side_stream(x.device)
             self.side.wait_stream(main)
             with ops.twin_branch(ops._RECORDER is None):   # both encoders walk the same shapes side by side: half the K slices each
                 with torch.cuda.stream(self.side):

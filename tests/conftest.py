@@ -109,6 +109,7 @@ _FORK_MODULES = ("test_production_gpu.py", "test_production_families_gpu.py", "t
 
 @pytest.fixture(autouse=True)
 def _single_branch_graphs_outside_the_graph_tests(request, monkeypatch):
-    if request.node.fspath.basename not in _FORK_MODULES and "SASPA_FORK" not in os.environ:
+    if (request.node.fspath.basename not in _FORK_MODULES and "SASPA_FORK" not in os.environ
+            and os.environ.get("SASPA_TEST_FORK_ALL", "0") != "1"):
         monkeypatch.setenv("SASPA_FORK", "0")
     yield

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared and set(declared) == set(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.saspa_abi_version() == 19 and lib.saspa_build_arch() == b"gfx950"
+    assert lib.saspa_abi_version() == 20 and lib.saspa_build_arch() == b"gfx950"
 
 
 def test_host_side_argument_validation_needs_no_gpu():

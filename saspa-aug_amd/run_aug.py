@@ -756,6 +756,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
             failed(batch, e)
             return False
         emit(batch, images, controls, resized, resized_subjects if subjects is not None else None)
+        batch_log.append((batch[0].height, batch[0].width, len(batch), _time.time()))
         return True
 
     def emit(batch, images, controls, sources, subjects):
@@ -772,6 +773,7 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
 
     import time as _time
     prof = os.environ.get("SASPA_PROFILE_LOOP") == "1"          # per-batch host timings in the log (diagnostics)
+    batch_log = []                                               # (height, width, items, t enqueue returned, t drained)
     if s.MAX_BATCHES > 0:
         batches = batches[:s.MAX_BATCHES]
     for bi, batch in enumerate(batches):
@@ -842,4 +844,4 @@ def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None,
     if dist is not None:
         dist.barrier()
     return dict(items=items, status=status, json_path=json_path, output_folder=output_folder, mine=mine, n_batches=len(batches),
-                png_submitted=png.submitted, png_max_queue=png.max_depth)
+                png_submitted=png.submitted, png_max_queue=png.max_depth, batch_log=batch_log)

@@ -99,17 +99,16 @@ def _release_gpu_state_between_modules():
 
 # Two-branch step graphs (SASPA_FORK, default on in the product) in a LONG multi-pipeline session: four of the five full `-m gpu`
 # sessions of round 5 ended in a segmentation fault inside the HIP runtime -- hip::GraphExec::Run -> hip::Graph::UpdateStreams
-# (rocgdb backtrace, profiles/EXPERIMENTS.md) -- at the replay of a tiny fp32 pipeline's graph ~490 tests in; each such test
-# passes alone, 300 live two-branch graphs in one process do not reproduce it (tools/graph_leak_probe.py), and the same session
-# with single-branch graphs passes.  The production path (one pipeline per process) has never shown it.  So: the two-branch form
-# stays on where it is what is being tested or measured (the production-size modules, which run first, and the graph tests);
-# every other module captures single-branch graphs.  A test that sets SASPA_FORK itself (monkeypatch) overrides this.
+# (profiles/r5_graph_replay_segv_backtrace.txt) -- ~490 tests in, and round 5 therefore captured single-branch graphs outside four
+# modules.  Round 6: every _StepGraph used to take its OWN capture side stream out of torch's stream pool; with ONE side stream per
+# process and device (pipeline.side_stream) the full session with two-branch graphs everywhere passes (profiles/r6_forkall_tests.log),
+# so the suite runs the product's default capture form again.  SASPA_TEST_SINGLE_BRANCH=1 restores the round-5 arrangement.
 _FORK_MODULES = ("test_production_gpu.py", "test_production_families_gpu.py", "test_graph_gpu.py", "test_config3_gpu.py")
 
 
 @pytest.fixture(autouse=True)
 def _single_branch_graphs_outside_the_graph_tests(request, monkeypatch):
-    if (request.node.fspath.basename not in _FORK_MODULES and "SASPA_FORK" not in os.environ
-            and os.environ.get("SASPA_TEST_FORK_ALL", "0") != "1"):
+    if (os.environ.get("SASPA_TEST_SINGLE_BRANCH", "0") == "1" and request.node.fspath.basename not in _FORK_MODULES
+            and "SASPA_FORK" not in os.environ):
         monkeypatch.setenv("SASPA_FORK", "0")
     yield

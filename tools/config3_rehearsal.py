@@ -215,6 +215,21 @@ class LocalWorld:
             g.zero_()
 
 
+def thread_cpu():
+    """{tid: (thread name, CPU seconds)} of this process from /proc (utime + stime per task)."""
+    tick = os.sysconf("SC_CLK_TCK")
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open(f"/proc/self/task/{tid}/stat").read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def mode_gpu(n_batches, out_json):
     import torch
     tmp = tempfile.mkdtemp(prefix="saspa_c3_")
@@ -239,14 +254,37 @@ def mode_gpu(n_batches, out_json):
         R.main(sw, pipe=pipe)
         t_warm = time.time() - t0
         ru0 = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+        th0 = thread_cpu()
         torch.cuda.synchronize()
         t0 = time.time()
         res = R.main(s, pipe=pipe, dist=LocalWorld(WORLD))
         torch.cuda.synchronize()
         dt = time.time() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+        th1 = thread_cpu()
         done = [it for it in res["mine"] if it.status == 1]
         n = len(done)
+        # CPU seconds per thread of THIS process over the run (threads that ended in between are not listed)
+        per_thread = sorted(((name, th1[t][1] - th0.get(t, (name, 0.0))[1], t == os.getpid()) for t, (name, _) in th1.items()),
+                            key=lambda r: -r[1])
+        threads = [dict(thread=("MAIN " if is_main else "") + name, cpu_s=round(c, 2), cpu_s_per_image=round(c / max(n, 1), 4))
+                   for name, c, is_main in per_thread if c > 0.005 * dt]
+        # images/s per (H, W) bucket: batches of one bucket are consecutive (make_batches sorts the buckets); a bucket's time runs
+        # from the drain of the previous bucket's last batch to the drain of its own last batch
+        per_bucket, prev_t, cur = [], t0, None
+        for (bh, bw, cnt, t) in res["batch_log"]:
+            if cur is None or cur["size"] != f"{bh}x{bw}":
+                if cur is not None:
+                    prev_t = cur["_t"]
+                cur = dict(size=f"{bh}x{bw}", batches=0, images=0, _t0=prev_t)
+                per_bucket.append(cur)
+            cur["batches"] += 1
+            cur["images"] += cnt
+            cur["_t"] = t
+        for c in per_bucket:
+            span = c.pop("_t") - c.pop("_t0")
+            c["seconds"] = round(span, 2)
+            c["images_per_s"] = round(c["images"] / span, 3) if span > 0 else None
         cpu_self = (ru1[0].ru_utime + ru1[0].ru_stime) - (ru0[0].ru_utime + ru0[0].ru_stime)
         cpu_child = (ru1[1].ru_utime + ru1[1].ru_stime) - (ru0[1].ru_utime + ru0[1].ru_stime)
         by_size = {}
@@ -266,6 +304,8 @@ def mode_gpu(n_batches, out_json):
             warmup_seconds_incl_graph_captures=round(t_warm, 1),
             png_files_submitted=res["png_submitted"], png_writer_max_backlog=res["png_max_queue"], png_writer_processes=4,
             host_cpu_s_per_image=dict(main_process=round(cpu_self / n, 4), png_writer_children=round(cpu_child / n, 4)),
+            main_process_threads=threads, per_bucket=per_bucket, failed_items=sum(1 for it in res["mine"] if it.status == -1),
+            env={k: os.environ[k] for k in ("SASPA_FORK", "SASPA_SIDE_STREAM", "OMP_NUM_THREADS") if k in os.environ},
             json_entries=len(body), json_paths_listed=listed, json_lists_only_generated=bool(listed == n),
             dtype="bf16", data="synthetic")
         print(json.dumps(out, indent=1))

@@ -51,6 +51,17 @@ class Recorder:
         self.items.append((kind, flops, e0, e1, meta))
         return r
 
+    def conditional(self, kind, flops, call, meta, keep):
+        """A launch the library may refuse (ops._probe_launch): recorded only when keep(result) says it really ran."""
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = call()
+        e1.record()
+        if keep(r):
+            self.items.append((kind, flops, e0, e1, meta))
+        return r
+
     @staticmethod
     def classify(kind, meta):
         """Launch class for `roofline.by_class`: the implicit-GEMM launches split by window (meta =

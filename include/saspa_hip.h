@@ -165,6 +165,10 @@ typedef struct SaspaGemmParams {
  * 16-byte aligned operands, ldo % 8 == 0): the only kernel that takes ln_gamma / out_t.  2 = the row blocks also fill whole
  * rounds of the 256 CUs (the sizes where it beats the other kernels on every layer shape), 1 = they do not. */
 int saspa_gemm_as_eligible(const SaspaGemmParams* p);
+/* ABI 20: 1 if saspa_gemm with variant AUTO will run THIS problem on the A-stationary kernel (the predicate dispatch itself uses):
+ * what a caller must ask before it plans around that choice -- e.g. dropping SaspaGemmParams.gn_stats, which that kernel's
+ * epilogue does not produce.  (saspa_gemm_as_eligible says whether the kernel CAN run it.) */
+int saspa_gemm_as_auto(const SaspaGemmParams* p);
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 /* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):
  * the caller allocates ksplit*M*N floats, sets p->ksplit / p->workspace and calls saspa_gemm.  Long-K layers with

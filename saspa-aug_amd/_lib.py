@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SASPA_HIP_LIB") or os.path.join(_HERE, "libsaspa_hip.so")
 
 SASPA_BF16, SASPA_F32, SASPA_F32X3 = 0, 1, 2
+SASPA_EINVAL, SASPA_EALIGN, SASPA_ERANGE = -1, -2, -3      # include/saspa_hip.h
 ERRORS = {-1: "SASPA_EINVAL (null pointer / bad size)", -2: "SASPA_EALIGN (16-byte alignment / channel multiple)",
           -3: "SASPA_ERANGE (unsupported shape)"}
 
@@ -88,6 +89,7 @@ SYMBOLS = {
     "saspa_gemm": (_I, [C.POINTER(GemmParams), _P]),
     "saspa_gemm_suggest_ksplit": (_I, [C.POINTER(GemmParams)]),
     "saspa_gemm_as_eligible": (_I, [C.POINTER(GemmParams)]),
+    "saspa_gemm_as_auto": (_I, [C.POINTER(GemmParams)]),
     "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),

@@ -34,5 +34,6 @@ __attribute__((visibility("hidden"))) bool saspa_gemm_ws_eligible(const SaspaGem
 // A-stationary kernel for K = 320 pointwise layers (saspa_gemm_as.hip): fused LayerNorm, transposed second output
 __attribute__((visibility("hidden"))) int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s);
 __attribute__((visibility("hidden"))) bool saspa_gemm_as_ok(const SaspaGemmParams& p);
+extern "C" int saspa_gemm_as_auto(const SaspaGemmParams* p);
 // channel slabs of the GroupNorm statistics pass for C / 8 chunks (saspa_norm.hip: layout of SaspaGroupNormParams.partial)
 __attribute__((visibility("hidden"))) int saspa_gn_slabs(int c8);

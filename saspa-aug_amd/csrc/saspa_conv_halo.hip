@@ -800,6 +800,10 @@ extern "C" int saspa_conv3x3_halo(const SaspaGemmParams* pp, const SaspaConvGnPa
   if (ks > geo.nper) ks = geo.nper;
   geo.per_slice = (geo.nper + ks - 1) / ks;
   ks = (geo.nper + geo.per_slice - 1) / geo.per_slice;           // no empty slices: the reduce sums exactly `ks` slabs
+  // ABI 19 contract of `defer_reduce`, as for saspa_gemm: the caller's saspa_splitk_groupnorm will sum EXACTLY p.ksplit slabs.  A
+  // launch that would end on one slice (it would write `out` directly) or on fewer slices than asked (uninitialised slabs would be
+  // summed) is refused; the caller sizes its request with saspa_conv3x3_halo_ksplit
+  if (p.defer_reduce && (ks <= 1 || ks != p.ksplit)) return SASPA_ERANGE;
   geo.gn_slabs = gp ? saspa_gn_slabs((p.c0 + p.c1) / 8) : 1;
   geo.ntiles = tiles;
   const int gx = saspa_balanced_grid(tiles, 256 / ks);

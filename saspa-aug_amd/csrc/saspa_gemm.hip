@@ -1067,14 +1067,8 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
   // kernel that takes a fused LayerNorm / a transposed second output
   if constexpr (sizeof(T) == 2) {
     if (p.variant == SASPA_GEMM_AS) return p.defer_reduce ? SASPA_ERANGE : saspa_gemm_as_launch(p, s);      // (no slabs on this kernel)
-    if (p.variant == SASPA_GEMM_AUTO && saspa_gemm_as_ok(p)) {
-      // a fused LayerNorm / transposed tail exists on this kernel only; otherwise it is taken where it measured faster than the
-      // tiled / wave-specialised kernels (tools/as_bench.py): whole rounds of 256-row blocks, or -- with a ragged last round
-      // (352 blocks at 512x704) -- the layers with a residual or 640 columns, not the GEGLU projection
-      const long long blocks = (p.M + 255) / 256;
-      const bool whole = blocks * 100 >= ((blocks + 255) / 256) * 256 * 85;
-      if (p.ln_gamma || p.out_t || whole || (p.act != SASPA_ACT_GEGLU && (p.residual || p.N >= 640))) return saspa_gemm_as_launch(p, s);
-    }
+    // AUTO: one predicate with the callers that plan around this choice (saspa_gemm_as_auto, saspa_gemm_as.hip)
+    if (saspa_gemm_as_auto(&p)) return saspa_gemm_as_launch(p, s);
   }
   if (p.ln_gamma || p.out_t || p.variant == SASPA_GEMM_AS) return SASPA_ERANGE;
   int ksplit = (p.workspace && p.ksplit > 1 && nb == 1 && p.N % 4 == 0) ? p.ksplit : 1;

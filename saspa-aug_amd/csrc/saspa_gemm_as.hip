@@ -510,6 +510,20 @@ int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s) {
 // on the GEGLU projection too (tools/as_bench.py).  Until round 5 that meant row blocks filling whole rounds of the 256 CUs
 // (>= 85 % of the last round: 352 blocks at 512x704 did not); with the steps dealt evenly every eligible size does.
 // SASPA_GEMM_BALANCE=0 restores the old launch and the old answer.
+// THE predicate "variant AUTO runs this problem on the A-stationary kernel" (round 6: shared by dispatch() in saspa_gemm.hip and
+// by callers that decide on it before the launch -- ops.conv drops the epilogue GroupNorm statistics only where this says yes;
+// saspa_gemm_as_eligible() alone said 2 for every size since the balanced launch, while dispatch() kept its measured rule).
+// A fused LayerNorm / transposed tail exists on this kernel only; otherwise it is taken where it measured faster than the tiled /
+// wave-specialised kernels (tools/as_bench.py): whole rounds of 256-row blocks, or -- with a ragged last round (352 blocks at
+// 512x704) -- the layers with a residual or >= 640 columns, not the GEGLU projection.
+extern "C" int saspa_gemm_as_auto(const SaspaGemmParams* pp) {
+  if (!pp || pp->variant != SASPA_GEMM_AUTO || pp->defer_reduce || !saspa_gemm_as_ok(*pp)) return 0;
+  const SaspaGemmParams& p = *pp;
+  const long long blocks = (p.M + 255) / 256;
+  const bool whole = blocks * 100 >= ((blocks + 255) / 256) * 256 * 85;
+  return (p.ln_gamma || p.out_t || whole || (p.act != SASPA_ACT_GEGLU && (p.residual || p.N >= 640))) ? 1 : 0;
+}
+
 extern "C" int saspa_gemm_as_eligible(const SaspaGemmParams* p) {
   if (!p || !saspa_gemm_as_ok(*p)) return 0;
   static const bool balance_off = getenv("SASPA_GEMM_BALANCE") && atoi(getenv("SASPA_GEMM_BALANCE")) == 0;

@@ -40,6 +40,24 @@ def _launch(kind, flops, call, meta=None):
     return _RECORDER(kind, flops, call, meta)
 
 
+def _probe_launch(kind, flops, call, meta=None):
+    """A launch that the library may REFUSE without launching anything (SASPA_ERANGE on a `defer_reduce` contract it cannot
+    honour): goes to the recorder only when it really ran (rc == 0) -- a refused probe used to be logged as a 2*M*N*K-FLOP
+    launch of ~zero duration and the fallback's real launch was logged again."""
+    if _RECORDER is None:
+        return call()
+    box = []
+
+    def run():
+        box.append(call())
+        return box[0]
+    rec = _RECORDER
+    if hasattr(rec, "conditional"):
+        return rec.conditional(kind, flops, run, meta, lambda rc: rc == 0)
+    rc = call()                      # a recorder without the hook: record nothing for the probe (under-counts one launch)
+    return rc
+
+
 def _dt(t):
     if t.dtype == torch.bfloat16:
         return _lib.SASPA_BF16
@@ -256,7 +274,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     # statistics epilogue, and A-stationary + the consumer's own statistics pass (27 + 12 us) beats the tiled kernel with the
     # statistics in its epilogue (53 us); SASPA_GEMM_AS_OVER_STATS=0 keeps the statistics
     if gn_unit and kh == 1 and kw == 1 and c1 == 0 and x.dtype == torch.bfloat16 and _as_over_stats() and \
-            lib.saspa_gemm_as_eligible(C.byref(p)) == 2:
+            lib.saspa_gemm_as_auto(C.byref(p)) == 1:
         gn_unit = None
     meta = (p.M, p.N, p.K, kh, stride, int(upsample), c1 > 0, residual is not None, n // 2 if act == ACT_GEGLU else n)
     if fuse_gn is not None:
@@ -275,11 +293,11 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
                 p.defer_reduce = 1
                 # SASPA_ERANGE: the dispatch would run this problem on ONE slice / a kernel without slabs (a variant pin, an A/B
                 # knob): nothing was launched, fall back to conv + groupnorm below
-                rc = _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: lib.saspa_gemm(C.byref(p), _stream()), meta)
+                rc = _probe_launch("gemm", 2.0 * p.M * p.N * p.K, lambda: lib.saspa_gemm(C.byref(p), _stream()), meta)
                 if rc == 0:
                     _launch("splitk_gn", 0.0, lambda: _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(q), _stream()), "saspa_splitk_groupnorm"))
                     return out
-                if rc != -3:
+                if rc != _lib.SASPA_ERANGE:
                     _lib.check(rc, "saspa_gemm(conv, deferred reduce)")
             p.ksplit, p.workspace, p.defer_reduce = 1, None, 0
         h = conv(x, w, bias, kh=kh, kw=kw, stride=stride, pad=pad, upsample=upsample, x2=x2, rowvec=rowvec, residual=residual, alpha=alpha,
@@ -387,7 +405,7 @@ def conv_gn(x, gn, w32, bias=None, *, x2=None, rowvec=None, residual=None, alpha
         g.gamma, g.beta = _ptr(gb32), _ptr(gb32)       # not read by the statistics pass
         g.partial, g.nsplit, g.scale_shift = _ptr(partial), nsplit, None
         g.act, g.y, g.ldy = 0, None, 0
-        _lib.check(lib.saspa_groupnorm_stats(C.byref(g), _stream()), "saspa_groupnorm_stats")
+        _launch("gn_stats", 0.0, lambda: _lib.check(lib.saspa_groupnorm_stats(C.byref(g), _stream()), "saspa_groupnorm_stats"))
         q.partial, q.nsplit = _ptr(partial), nsplit
         keep.append(partial)
     if out is None:
@@ -425,9 +443,12 @@ def conv_gn(x, gn, w32, bias=None, *, x2=None, rowvec=None, residual=None, alpha
             g2.act, g2.y, g2.ldy = int(gact2), _ptr(out), _pitch4(out)
             if p.ksplit > 1 and lib.saspa_splitk_groupnorm_eligible(C.byref(p), C.byref(g2)):
                 p.defer_reduce = 1
-                _launch("gemm", flops, lambda: _lib.check(lib.saspa_conv3x3_halo(C.byref(p), qq, _stream()), "saspa_conv3x3_halo(deferred reduce)"), meta)
-                _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(g2), _stream()), "saspa_splitk_groupnorm")
-                return out
+                rc = _probe_launch("gemm", flops, lambda: lib.saspa_conv3x3_halo(C.byref(p), qq, _stream()), meta)
+                if rc == 0:
+                    _launch("splitk_gn", 0.0, lambda: _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(g2), _stream()), "saspa_splitk_groupnorm"))
+                    return out
+                if rc != _lib.SASPA_ERANGE:
+                    _lib.check(rc, "saspa_conv3x3_halo(deferred reduce)")
             p.ksplit, p.workspace, p.defer_reduce = 1, None, 0
         _gs = _gn_stats_for(p, out, gn_unit, b, h * wd, n)  # noqa: F841
         _ws = _split(ksplit)  # noqa: F841

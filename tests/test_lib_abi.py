@@ -58,6 +58,17 @@ def test_host_side_argument_validation_needs_no_gpu():
     h.c0, h.c1, h.N, h.K, h.M, h.ldw, h.lda0, h.ldo, h.korder, h.nb1, h.nb2 = 320, 0, 640, 2880, 512, 2880, 320, 640, 2, 1, 1
     assert lib.saspa_conv3x3_halo_eligible(C.byref(h), None) == 1
     assert lib.saspa_conv3x3_halo_ksplit(C.byref(h), 3) == 3 and lib.saspa_conv3x3_halo_ksplit(C.byref(h), 4) == 3   # 5 chunk pairs: 2 + 2 + 1
+    # the `defer_reduce` contract of the halo conv (advisor, round 5): a deferred reduce that would end on ONE slice, or on fewer
+    # slices than the caller's saspa_splitk_groupnorm will sum, is refused before anything is launched
+    big = (C.c_char * 64)()
+    ptr = (C.addressof(big) + 15) // 16 * 16
+    h.a0 = h.w = h.out = h.workspace = ptr
+    h.defer_reduce, h.ksplit = 1, 1
+    assert lib.saspa_conv3x3_halo(C.byref(h), None, None) == -3
+    h.ksplit = 4                                                                                                   # lands on 3 slices
+    assert lib.saspa_conv3x3_halo(C.byref(h), None, None) == -3
+    h.a0 = h.w = h.out = h.workspace = None
+    h.defer_reduce, h.ksplit = 0, 1
     h.korder = 1
     assert lib.saspa_conv3x3_halo_eligible(C.byref(h), None) == 0                                                  # im2col packing
     h.korder, h.hin, h.hout = 2, 8, 8
@@ -68,6 +79,37 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert lib.saspa_flash_attn_bf16(C.byref(q), None) == -1
     assert lib.saspa_canny(None, None, None, 1, 8, 8, 1, 2, None) == -1
     assert lib.saspa_canny(base, base, (base + 15) // 16 * 16, 1, 100000, 32, 1, 2, None) == -3   # bitmaps exceed LDS and W < 64
+
+
+def test_as_auto_is_the_dispatch_predicate_not_mere_eligibility():
+    """ABI 20 (advisor, round 5): `saspa_gemm_as_eligible` says 2 for every size the balanced A-stationary launch can take, but AUTO
+    keeps its measured rule -- a ragged block count (352 blocks of 256 rows: 512x704) without LayerNorm / residual and with 320
+    columns stays on the tiled kernel.  Callers that plan around the choice (ops.conv drops the epilogue GroupNorm statistics)
+    ask `saspa_gemm_as_auto`, the predicate dispatch() itself uses."""
+    lib = _lib.load()
+    keep = []
+
+    def mk(m, n=320, res=False, act=0):
+        p = _lib.GemmParams()
+        a = (C.c_char * 64)()
+        keep.append(a)
+        base = (C.addressof(a) + 15) // 16 * 16
+        p.a0 = p.w = p.out = base
+        if res:
+            p.residual, p.ldr = base, n
+        p.dtype, p.M, p.N, p.K, p.batch = _lib.SASPA_BF16, m, n, 320, 1
+        p.kh = p.kw = p.stride = 1
+        p.c0 = p.lda0 = p.ldw = 320
+        p.ldo, p.hin, p.hout, p.win, p.wout, p.nb1, p.nb2, p.alpha, p.act = n, m, m, 1, 1, 1, 1, 1.0, act
+        return p
+    for m, n, res, act, elig, auto in [(65536, 320, False, 0, 2, 1), (352 * 256, 320, False, 0, 2, 0), (352 * 256, 320, True, 0, 2, 1),
+                                       (352 * 256, 640, False, 0, 2, 1), (352 * 256, 2560, False, 3, 2, 0), (100 * 256, 320, False, 0, 0, 0)]:
+        p = mk(m, n, res, act)
+        assert lib.saspa_gemm_as_eligible(C.byref(p)) == elig, (m, n, res)
+        assert lib.saspa_gemm_as_auto(C.byref(p)) == auto, (m, n, res)
+    p = mk(65536)
+    p.variant = 1                                   # pinned to the tiled kernel: AUTO's choice does not apply
+    assert lib.saspa_gemm_as_auto(C.byref(p)) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

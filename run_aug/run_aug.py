@@ -4,7 +4,13 @@ the reference's run_aug/run_aug.py:513-556) and run
 
     python run_aug/run_aug.py                                   # one MI355X
     SASPA_GPUS=8 python run_aug/run_aug.py                      # 8 MI355X: this script starts the 8 ranks itself
+    SASPA_SUPERVISE=1 python run_aug/run_aug.py                 # one MI355X under the supervising launcher (see below)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_aug/run_aug.py   # same, via torchrun
+
+Started through this script's own launcher (SASPA_GPUS > 1, or SASPA_SUPERVISE=1 for a single GPU) the run is supervised:
+if a rank dies on a signal -- the HIP runtime's graph-replay crash of long sessions, DESIGN.md section 7 -- all ranks are
+started again ONCE as fresh processes with SASPA_FORK=0 (single-branch step graphs) and continue from the files that
+exist; the exit code is non-zero if that fails too.  SASPA_FORK=0 by hand rules the two-branch capture out from the start.
 
 Environment overlays (optional): SASPA_DATASET, SASPA_WEIGHTS_DIR, SASPA_PROMPTS_FILE,
 SASPA_NUM_INFERENCE_STEPS, SASPA_NUM_PER_IMAGE, SASPA_PRECISION, SASPA_BASE_MODEL (sd_v1.5 | blip_diffusion | sd_xl-turbo)."""
@@ -16,10 +22,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 import saspa_aug_amd  # noqa: E402,F401
 
-if __name__ == "__main__" and int(os.environ.get("SASPA_GPUS", "1")) > 1 and "WORLD_SIZE" not in os.environ:
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and \
+        (int(os.environ.get("SASPA_GPUS", "1")) > 1 or os.environ.get("SASPA_SUPERVISE", "0") == "1"):
     # become the launcher BEFORE torch is imported: the parent never touches the GPU (saspa_aug_amd/launcher.py)
-    from saspa_aug_amd.launcher import launch_ranks  # noqa: E402
-    sys.exit(launch_ranks(int(os.environ["SASPA_GPUS"]), __file__, sys.argv[1:]))
+    from saspa_aug_amd.launcher import launch_supervised  # noqa: E402
+    sys.exit(launch_supervised(int(os.environ.get("SASPA_GPUS", "1")), __file__, sys.argv[1:]))
 
 from saspa_aug_amd import run_aug as R  # noqa: E402
 

@@ -17,6 +17,26 @@ def free_port():
         return s.getsockname()[1]
 
 
+def launch_supervised(n, script, argv, fallback_env=None, max_restarts=1):
+    """`launch_ranks`, plus ONE supervised restart for a generation run (round 6, advisor finding on the two-branch step
+    graphs): when a rank is killed by a SIGNAL (negative return code -- e.g. the segmentation fault inside hipGraphLaunch that
+    long multi-pipeline sessions showed on ROCm 7.2, profiles/r5_graph_replay_segv_backtrace.txt), every rank is started again
+    as a FRESH child process with `fallback_env` (default SASPA_FORK=0: single-branch step graphs, -4.7 % at 512x512) on top
+    of the environment.  A generation run is resumable by construction -- `plan_work` skips every output file that exists
+    (run_aug/run_aug.py:430-432) -- so the restart continues where the dead run stopped.  Never an exec of this or of a
+    GPU-holding process; an ordinary failure (positive exit code) is not retried and is returned as it is."""
+    fallback_env = {"SASPA_FORK": "0"} if fallback_env is None else dict(fallback_env)
+    rc = launch_ranks(n, script, argv)
+    restarts = 0
+    while rc < 0 and restarts < max_restarts:
+        restarts += 1
+        print(f"launcher: a rank died on signal {-rc}; restarting all {n} rank(s) in fresh processes with "
+              f"{' '.join(f'{k}={v}' for k, v in fallback_env.items())} (restart {restarts} of {max_restarts}; finished files are skipped)",
+              file=sys.stderr, flush=True)
+        rc = launch_ranks(n, script, argv, extra_env=fallback_env)
+    return rc
+
+
 def launch_ranks(n, script, argv, extra_env=None):
     """Run `python script argv...` as ranks 0..n-1; returns the exit code (0 only if every rank exited 0).  As soon as
     one rank fails the others are terminated by PID (they would otherwise wait at the rendezvous forever)."""

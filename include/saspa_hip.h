@@ -169,6 +169,10 @@ int saspa_gemm_as_eligible(const SaspaGemmParams* p);
  * what a caller must ask before it plans around that choice -- e.g. dropping SaspaGemmParams.gn_stats, which that kernel's
  * epilogue does not produce.  (saspa_gemm_as_eligible says whether the kernel CAN run it.) */
 int saspa_gemm_as_auto(const SaspaGemmParams* p);
+/* ABI 20: which kernel family saspa_gemm would run `p` on and on how many K slices: the dispatch executed DRY (same validation, nothing
+ * launched, `stream` not needed).  Returns family | (ksplit << 8), family = SASPA_GEMM_TILED / WIDE / WS / AS, or the SASPA_E* code
+ * saspa_gemm would return.  Measurement aid: bench.py attributes every recorded launch to its kernel (roofline.dominant). */
+int saspa_gemm_which(const SaspaGemmParams* p);
 int saspa_gemm(const SaspaGemmParams* p, void* stream);
 /* The library's recommended K-split factor for a problem (1 = none; every field but ksplit / workspace filled in):
  * the caller allocates ksplit*M*N floats, sets p->ksplit / p->workspace and calls saspa_gemm.  Long-K layers with

@@ -90,6 +90,7 @@ SYMBOLS = {
     "saspa_gemm_suggest_ksplit": (_I, [C.POINTER(GemmParams)]),
     "saspa_gemm_as_eligible": (_I, [C.POINTER(GemmParams)]),
     "saspa_gemm_as_auto": (_I, [C.POINTER(GemmParams)]),
+    "saspa_gemm_which": (_I, [C.POINTER(GemmParams)]),
     "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),

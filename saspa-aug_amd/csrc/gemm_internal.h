@@ -7,6 +7,11 @@
 
 // 8-wave 256 x (64*fn) ping-pong kernel (saspa_gemm_pp.hip).  bf16, "fast" operand layout only
 // (see saspa_gemm.hip); fn in {4, 5}.  Returns SASPA_ERANGE if the problem is not eligible.
+// Dry dispatch (ABI 20, saspa_gemm_which): with `on` set for the calling thread, the kernel launchers below record which kernel family
+// (SASPA_GEMM_TILED / WIDE / WS / AS = SaspaGemmParams.variant codes) and how many K slices dispatch() chose and return WITHOUT launching.
+struct SaspaDryRun { bool on; int family; int ksplit; };
+__attribute__((visibility("hidden"))) SaspaDryRun* saspa_dry_state();     // the calling thread's (saspa_gemm.hip)
+#define SASPA_DRY_RETURN(fam_, ks_) do { SaspaDryRun* d_ = saspa_dry_state(); if (d_->on) { d_->family = (fam_); d_->ksplit = (ks_); return 0; } } while (0)
 __attribute__((visibility("hidden"))) int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn);
 __attribute__((visibility("hidden"))) bool saspa_gemm_pp_eligible(const SaspaGemmParams& p);
 // split-K reduce + epilogue launch shared by both variants (saspa_gemm.hip)

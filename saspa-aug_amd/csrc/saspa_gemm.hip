@@ -34,6 +34,11 @@ constexpr bool KORDER_ON = false;   // A/B build: the K walk exactly as before A
 constexpr bool KORDER_ON = true;
 #endif
 
+SaspaDryRun* saspa_dry_state() {      // dry dispatch state of the calling thread (gemm_internal.h)
+  static thread_local SaspaDryRun st = {false, 0, 0};
+  return &st;
+}
+
 namespace {
 
 template <typename T> struct Mma;
@@ -978,6 +983,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const SaspaGem
 template <typename T, int WM, int WN, int NWM = 2, int NWN = 2>
 int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   constexpr int BM = 16 * WM * NWM, BN = 16 * WN * NWN, NT = 64 * NWM * NWN;
+  SASPA_DRY_RETURN(SASPA_GEMM_TILED, ksplit);
   const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   // persistent grid: as many workgroups as the chip keeps resident (256 CUs x blocks/CU by LDS / VGPR budget)
   constexpr int kResident = 256 * (NT > 256 ? 1 : ((BM + BN) * 256 > 48 * 1024 ? 2 : 4));
@@ -1282,6 +1288,19 @@ int saspa_gemm_splitk_reduce(const SaspaGemmParams& p, hipStream_t s, int ksplit
   else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, p, ksplit);
   SASPA_CHECK_LAUNCH();
   return 0;
+}
+
+/* ABI 20: which kernel family saspa_gemm would run `p` on, and on how many K slices -- the dispatch itself, executed dry (nothing is
+ * launched).  Returns family | (ksplit << 8) with family = SASPA_GEMM_TILED / WIDE / WS / AS, or the SASPA_E* code saspa_gemm would
+ * return.  bench.py attributes every recorded launch to its kernel with this (roofline.by_kernel / roofline.dominant). */
+extern "C" int saspa_gemm_which(const SaspaGemmParams* pp) {
+  SaspaDryRun* st = saspa_dry_state();
+  *st = {true, 0, 1};
+  const int rc = saspa_gemm(pp, nullptr);
+  const SaspaDryRun d = *st;
+  *st = {false, 0, 0};
+  if (rc != 0) return rc;
+  return d.family | (d.ksplit << 8);
 }
 
 extern "C" int saspa_gemm(const SaspaGemmParams* pp, void* stream) {

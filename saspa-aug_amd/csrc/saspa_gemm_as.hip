@@ -486,6 +486,7 @@ bool saspa_gemm_as_ok(const SaspaGemmParams& p) {
 
 int saspa_gemm_as_launch(const SaspaGemmParams& p, hipStream_t s) {
   if (!saspa_gemm_as_ok(p)) return SASPA_ERANGE;
+  SASPA_DRY_RETURN(SASPA_GEMM_AS, 1);
   // one workgroup per CU, the steps dealt evenly (see the kernel); SASPA_GEMM_BALANCE=0: one workgroup per row block as before
   const long long nblk = (p.M + AS_BM - 1) / AS_BM, steps = nblk * (p.N / AS_BN);
   static const bool balance_off = getenv("SASPA_GEMM_BALANCE") && atoi(getenv("SASPA_GEMM_BALANCE")) == 0;

@@ -1043,6 +1043,7 @@ bool saspa_gemm_pp_eligible(const SaspaGemmParams& p) {
 
 int saspa_gemm_pp_launch(const SaspaGemmParams& p, hipStream_t s, int ksplit, int fn) {
   if (!saspa_gemm_pp_eligible(p)) return SASPA_ERANGE;
+  SASPA_DRY_RETURN(SASPA_GEMM_WIDE, ksplit);
   // K loop flavour (read per launch; all are bit-identical: same MFMA order per accumulator):
   //   SASPA_GEMM_PP_LOOP=2 (default since round 5)  two-barrier ping-pong, TWO 40-MFMA intervals per K-tile: +2 ... +8 % on every
   //                         shape against =0 (tools/pp_ab.py, profiles/r5_pp_long_ab.txt)

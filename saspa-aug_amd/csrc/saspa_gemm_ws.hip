@@ -462,6 +462,7 @@ bool saspa_gemm_ws_eligible(const SaspaGemmParams& p) {
 
 int saspa_gemm_ws_launch(const SaspaGemmParams& p, hipStream_t s) {
   if (!saspa_gemm_ws_eligible(p)) return SASPA_ERANGE;
+  SASPA_DRY_RETURN(SASPA_GEMM_WS, 1);
   const bool n160 = (p.N % 160) == 0;
   const int bn = n160 ? 160 : 128;
   const int tiles = ((p.N + bn - 1) / bn) * ((p.M + 127) / 128);

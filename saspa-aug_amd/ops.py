@@ -40,6 +40,18 @@ def _launch(kind, flops, call, meta=None):
     return _RECORDER(kind, flops, call, meta)
 
 
+GEMM_FAMILY_NAMES = {1: "tiled_4wave", 2: "wide_8wave", 3: "wave_specialised", 4: "a_stationary"}
+
+
+def _meta_kernel(p, meta):
+    """Recorder runs only: append (kernel family, K slices) of the launch `p` describes -- the library's own dispatch, executed dry
+    (saspa_gemm_which) -- to the launch's meta tuple, so that per-launch timings can be grouped by the kernel that really ran."""
+    if _RECORDER is None or meta is None:
+        return meta
+    w = int(_lib.load().saspa_gemm_which(C.byref(p)))
+    return tuple(meta) + ((w & 0xff, w >> 8) if w > 0 else (0, 1))
+
+
 def _probe_launch(kind, flops, call, meta=None):
     """A launch that the library may REFUSE without launching anything (SASPA_ERANGE on a `defer_reduce` contract it cannot
     honour): goes to the recorder only when it really ran (rc == 0) -- a refused probe used to be logged as a 2*M*N*K-FLOP
@@ -293,7 +305,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
                 p.defer_reduce = 1
                 # SASPA_ERANGE: the dispatch would run this problem on ONE slice / a kernel without slabs (a variant pin, an A/B
                 # knob): nothing was launched, fall back to conv + groupnorm below
-                rc = _probe_launch("gemm", 2.0 * p.M * p.N * p.K, lambda: lib.saspa_gemm(C.byref(p), _stream()), meta)
+                rc = _probe_launch("gemm", 2.0 * p.M * p.N * p.K, lambda: lib.saspa_gemm(C.byref(p), _stream()), _meta_kernel(p, meta))
                 if rc == 0:
                     _launch("splitk_gn", 0.0, lambda: _lib.check(lib.saspa_splitk_groupnorm(C.byref(p), C.byref(q), _stream()), "saspa_splitk_groupnorm"))
                     return out
@@ -305,7 +317,7 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
         return groupnorm(h, gamma, beta, groups, eps, gact)
     _gs = _gn_stats_for(p, out, gn_unit, b, ho * wo, n)  # noqa: F841   (set BEFORE the split-K heuristic looks at p)
     _ws = _set_splitk(p, p.M, p.N, p.K, x, ksplit)  # noqa: F841   (ksplit: tuning override of the heuristic)
-    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"), meta)
+    _launch("gemm", 2.0 * p.M * p.N * p.K, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(conv)"), _meta_kernel(p, meta))
     return out
 
 
@@ -532,7 +544,7 @@ def linear(x, w, bias=None, *, residual=None, alpha=1.0, act=ACT_NONE, out=None,
     if act == ACT_GEGLU:
         p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(linear)"),
-            (m, n, k, 0, 1, 0, False, residual is not None, n // 2 if act == ACT_GEGLU else n))
+            _meta_kernel(p, (m, n, k, 0, 1, 0, False, residual is not None, n // 2 if act == ACT_GEGLU else n)))
     if x.dim() != 2 and out.dim() == 2:
         return out.reshape(*x.shape[:-1], out.shape[-1])
     return out
@@ -599,7 +611,8 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     p.so1, p.so2 = so
     p.ksplit, p.workspace = 1, None
     _launch("gemm", 2.0 * m * n * k * nb1 * nb2,
-            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"), (m, n, k, -nb1 * nb2, 1, 0, False, residual is not None, n))
+            lambda: _lib.check(lib.saspa_gemm(C.byref(p), _stream()), "saspa_gemm(batched)"),
+            _meta_kernel(p, (m, n, k, -nb1 * nb2, 1, 0, False, residual is not None, n)))
     return out
 
 

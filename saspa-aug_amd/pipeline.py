@@ -46,6 +46,14 @@ def fork_enabled():
     return os.environ.get("SASPA_FORK", "1") != "0"
 
 
+def replay_queue_depth():
+    """Replays of the step graph the host keeps outstanding before it sleeps on a blocking event (see _StepGraph.run)."""
+    try:
+        return int(os.environ.get("SASPA_REPLAY_DEPTH", "3"))
+    except ValueError:
+        return 3
+
+
 _SIDE_STREAMS = {}
 
 
@@ -96,6 +104,7 @@ class _StepGraph:
         self.tables, self.curs, self.ctx_kv = [], [], []
         self.graph = None
         self.side = None                  # second capture stream of the forked step (fork_enabled)
+        self._replay_events = []          # blocking events of the replays still in the queue (run())
 
     def _bind(self):
         """Point the networks at this graph's static state."""
@@ -199,8 +208,24 @@ class _StepGraph:
             with torch.cuda.graph(g):
                 self._step()
             self.graph = g
+        depth = replay_queue_depth()
+        if depth <= 0:
+            for _ in range(self.evals):
+                self.graph.replay()
+            return self.x
+        # Host throttle (round 6): the HIP queue holds about five replays of the ~1 500-node step; once it is full, hipGraphLaunch
+        # SPINS on the calling thread until a slot frees -- one host core per rank at 100 % for the whole run
+        # (profiles/r6_config3_full_shard.json: 0.21 CPU-s per image in the launch thread alone).  Keeping at most `depth` replays
+        # outstanding behind BLOCKING events (hipEventBlockingSync: the thread sleeps in the driver) leaves the GPU the same backlog
+        # to chew on (3 replays = 70-100 ms) and gives the core back.  SASPA_REPLAY_DEPTH=0 restores the unthrottled loop.
+        evs = self._replay_events
         for _ in range(self.evals):
+            if len(evs) >= depth:
+                evs.pop(0).synchronize()
             self.graph.replay()
+            e = torch.cuda.Event(blocking=True)
+            e.record()
+            evs.append(e)
         return self.x
 
 
@@ -357,9 +382,30 @@ class StableDiffusionControlNetPipeline:
             net.prepare_context(ctx)
         eps = torch.zeros_like(x2)
 
+        rec = ops._RECORDER
+        twin_rec = rec is not None and getattr(rec, "twin", False) and self.controlnet is not None and fork_enabled()
+        gate = torch.zeros(2, dtype=torch.int64, device=x2.device) if twin_rec else None
+
         def evaluate(i):
             if self.controlnet is None:
                 mid, skips = self.unet.encode(x2, i)
+            elif twin_rec:
+                # a launch recorder that wants the TIMED path's dispatch (bench.Recorder(twin=True)): the two encoders on two streams
+                # with the shared-chip hint, as the captured step runs them.  Both streams are held behind one sleeping wave
+                # (ops.clock_probe, ~40 ms) until the host has enqueued both launch sequences, so that they really run side by side
+                main, side = torch.cuda.current_stream(), side_stream(x2.device)
+                ops.clock_probe(gate, 10000)
+                side.wait_stream(main)
+                rec.begin_twin()
+                with ops.twin_branch(True):
+                    with torch.cuda.stream(side):
+                        cmid, cfeats = self.controlnet.encode(x2, i, conv_in_residual=cemb2)
+                    mid, skips = self.unet.encode(x2, i)
+                rec.end_twin()
+                main.wait_stream(side)
+                for t in (cmid, *cfeats):
+                    t.record_stream(main)
+                skips, mid = self.controlnet.zero_convs(cmid, cfeats, cscale, skips, mid)
             else:
                 # the same launches, with the same dispatch decisions, as the two-branch graph step (_StepGraph._step): the
                 # split-K of the paired encoders is sized for two concurrent branches (ops.twin_branch) -- except under a

@@ -630,10 +630,24 @@ def hip_batch_generator(pipe, s: Settings):
         with torch.cuda.stream(side):
             for t in (out, src) + ((ctrl,) if ctrl is not None else ()) + tuple(subs or ()):
                 t.record_stream(side)
-            o, sr = out.cpu(), src.cpu()
-            c = ctrl.cpu() if ctrl is not None else None
-            sb = [t.cpu().numpy() for t in subs] if subs is not None else None
-        return o.numpy(), (c.numpy() if c is not None else None), sr.numpy(), sb
+            if os.environ.get("SASPA_HOST_BLOCKING", "1") == "0":
+                o, sr = out.cpu(), src.cpu()                    # (a synchronous copy spins on the calling thread until the batch is done)
+                c = ctrl.cpu() if ctrl is not None else None
+                sb = [t.cpu() for t in subs] if subs is not None else None
+            else:
+                # asynchronous copies into pinned buffers, then ONE wait on a blocking event: the thread sleeps in the driver for the
+                # rest of the batch instead of spinning (round 6: host budget of 8 ranks on a 16-core quota)
+                def d2h(t):
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    return h
+                o, sr = d2h(out), d2h(src)
+                c = d2h(ctrl) if ctrl is not None else None
+                sb = [d2h(t) for t in subs] if subs is not None else None
+                done = torch.cuda.Event(blocking=True)
+                done.record()
+                done.synchronize()
+        return o.numpy(), (c.numpy() if c is not None else None), sr.numpy(), ([t.numpy() for t in sb] if sb is not None else None)
 
     def run(batch, noises, sources, subjects=None, category=None):
         return finish(enqueue(batch, noises, sources, subjects, category))
@@ -654,7 +668,37 @@ def load_source(path, resolution):
     return utils.resize_image(load_raw(path), resolution)
 
 
+def host_threads(local_world=1):
+    """Intra-op threads a generation rank gives torch's CPU pool: min(4, CPU quota / ranks on this node), SASPA_HOST_THREADS
+    overrides.  torch sizes the pool to the machine (128 threads on the 256-logical-CPU MI355X hosts, whatever the cgroup quota);
+    the loop's small CPU tensor ops (noise slices, pinned staging copies, token arrays) woke all of them and each spun in OpenMP's
+    wait loop afterwards: 128 x 2.7 s = 0.21 CPU-s per image, a third of the main process' CPU time
+    (profiles/r6_config3_full_shard.json).  Nothing on the generation path is CPU-compute-bound."""
+    env = os.environ.get("SASPA_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(4, n // max(1, int(local_world))))
+
+
 def main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None, filter_models=None):
+    """`_main` with torch's CPU pool held at `host_threads()` for the duration of the run (restored afterwards)."""
+    world = dist.get_world_size() if dist is not None else 1
+    before = torch.get_num_threads()
+    torch.set_num_threads(host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    try:
+        return _main(s, ds_utils=ds_utils, batch_generator=batch_generator, dist=dist, pipe=pipe, filter_models=filter_models)
+    finally:
+        torch.set_num_threads(before)
+
+
+def _main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None, filter_models=None):
     """The generation loop.  `batch_generator` is injectable for host-logic tests; the default
     builds the HIP pipeline (fails loudly without an MI355X).  `filter_models` = (SemanticFilter | None,
     ConfidenceFilter | None) to reuse built filter models; None builds them on s.DEVICE when a filter flag is set."""

@@ -112,6 +112,35 @@ def test_as_auto_is_the_dispatch_predicate_not_mere_eligibility():
     assert lib.saspa_gemm_as_auto(C.byref(p)) == 0
 
 
+def test_gemm_which_is_a_dry_dispatch():
+    """ABI 20: saspa_gemm_which runs saspa_gemm's validation and dispatch without launching anything (no GPU needed) and reports
+    family | (ksplit << 8): the level-0 3x3 conv goes to the 8-wave kernel, a K = 320 pointwise layer with a residual to the
+    A-stationary one, (16384, 640, 640) to the 4-wave tiles, (4096, 1280, 1280) to the wave-specialised kernel; invalid
+    problems return saspa_gemm's own error code."""
+    lib = _lib.load()
+    a = (C.c_char * 64)()
+    base = (C.addressof(a) + 15) // 16 * 16
+
+    def conv(b, h, w, cin, n, kh=3, res=False):
+        p = _lib.GemmParams()
+        p.a0 = p.w = p.out = base
+        p.dtype, p.batch, p.hin, p.hout, p.win, p.wout, p.kh, p.kw, p.stride, p.pad = _lib.SASPA_BF16, b, h, h, w, w, kh, kh, 1, kh // 2
+        p.c0 = p.lda0 = cin
+        p.K = p.ldw = kh * kh * cin
+        p.N = p.ldo = n
+        p.M, p.nb1, p.nb2, p.alpha = b * h * w, 1, 1, 1.0
+        if res:
+            p.residual, p.ldr = base, n
+        return p
+    for args, fam in [((16, 64, 64, 320, 320), 2), ((16, 64, 64, 320, 320, 1, True), 4), ((16, 32, 32, 640, 640, 1), 1), ((16, 16, 16, 1280, 1280, 1), 3)]:
+        w = lib.saspa_gemm_which(C.byref(conv(*args)))
+        assert (w & 0xff, w >> 8) == (fam, 1), (args, w)
+    bad = conv(16, 64, 64, 320, 320)
+    bad.K = 99
+    assert lib.saspa_gemm_which(C.byref(bad)) == -3
+    assert lib.saspa_gemm_which(None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

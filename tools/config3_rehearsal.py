@@ -255,6 +255,23 @@ def mode_gpu(n_batches, out_json):
         t_warm = time.time() - t0
         ru0 = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
         th0 = thread_cpu()
+        if os.environ.get("SASPA_STACKS_AT"):
+            # diagnostics: N seconds into the run, native stacks of every thread (rocgdb attached from a child for a moment) next to
+            # the per-thread CPU times so far -> which thread spins, and where
+            import ctypes
+            import subprocess
+            import threading
+            ctypes.CDLL(None).prctl(0x59616d61, ctypes.c_ulong(-1 & (2 ** 64 - 1)), 0, 0, 0)          # PR_SET_PTRACER, ANY
+
+            def stacks():
+                time.sleep(float(os.environ["SASPA_STACKS_AT"]))
+                busy = sorted(((c - th0.get(t, (n, 0.0))[1], t, n) for t, (n, c) in thread_cpu().items()), reverse=True)[:4]
+                with open("gpurun_out/r6_host_thread_stacks.txt", "w") as f:
+                    f.write("busiest threads (cpu s since start, tid, name): " + repr(busy) + "\n")
+                    f.flush()
+                    subprocess.run(["rocgdb", "-p", str(os.getpid()), "-batch", "-ex", "info threads", "-ex", "thread apply all bt 14"],
+                                   stdout=f, stderr=subprocess.STDOUT, timeout=240)
+            threading.Thread(target=stacks, daemon=True).start()
         torch.cuda.synchronize()
         t0 = time.time()
         res = R.main(s, pipe=pipe, dist=LocalWorld(WORLD))

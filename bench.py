@@ -31,7 +31,10 @@ sys.path.insert(0, ROOT)
 # its N rank processes BEFORE anything in this (parent) process can touch the GPU.
 
 BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
-RECORDER_NOTE = ("The recorder times every launch on its own stream position from the eager loop.")
+RECORDER_NOTE = ("Every launch is timed by a HIP event pair in the eager loop; the paired UNet / ControlNet encoders run on two streams with "
+                 "the shared-chip dispatch (SaspaGemmParams.sharing = 1) exactly as in the captured step, and a launch of such a pair is "
+                 "charged duration x (pair wall time / sum of the pair's durations) -- `timed_path_check` compares the table's total "
+                 "with the timed region.")
 MFMA_SUSTAINED_TFLOPS = 2000.0        # measured, random operands, power-limited (profiles/r5_mfma_microbench.txt)
 F_IMG_50 = 109.33e12               # algorithmic FLOP / 512x512 image at 50 steps
 
@@ -553,10 +556,14 @@ def run(args):
     # ---- roofline of the dominant kernel family (HIP events around every launch, one evaluation) ----
     roof = None
     if rank == 0:
-        rec = Recorder()
+        # twin=True: the recorded eager evaluation runs the two encoders on two streams with the shared-chip dispatch, like the
+        # captured step of the timed region, and charges the paired launches their share of the pair's wall time
+        rec, rec1 = Recorder(twin=True), Recorder(twin=True)
         imgs, ids, lat_dev = batches[0]
         ctrl = ops.canny(imgs, 120, 200)
         pipe.generate_batch(ids, neg, ctrl, lat_dev, 1, 7.5, 0.75, latents_on_device=True)   # warm
+        ops.set_recorder(rec1)
+        pipe.generate_batch(ids, neg, ctrl, lat_dev, 1, 7.5, 0.75, latents_on_device=True)
         ops.set_recorder(rec)
         pipe.generate_batch(ids, neg, ctrl, lat_dev, 2, 7.5, 0.75, latents_on_device=True)
         ops.set_recorder(None)
@@ -656,6 +663,17 @@ def run(args):
                     roof["traffic_by_kernel"] = tj["by_kernel"]
             except Exception:  # a malformed profile file must not take the bench line down
                 pass
+        # does the per-launch table describe the timed path?  charged time of ONE sampling step = (2-step run) - (1-step run); a batch of
+        # the timed region should then take fixed + ddim_steps x step
+        t2, t1 = sum(rec.charged_ms()), sum(rec1.charged_ms())
+        step_ms, fixed_ms = t2 - t1, 2 * t1 - t2
+        pred = fixed_ms + s * step_ms
+        roof["timed_path_check"] = dict(recorded_ms_per_sampling_step=round(step_ms, 3), recorded_fixed_ms_per_batch=round(fixed_ms, 2),
+                                        predicted_ms_per_batch=round(pred, 1), measured_ms_per_batch=round(dt / args.steps * 1e3, 1),
+                                        predicted_over_measured=round(pred / (dt / args.steps * 1e3), 4),
+                                        twin_regions=len(getattr(rec, "twin_regions", [])),
+                                        what="sum of the charged times of every recorded launch (all kinds), eager loop with the production "
+                                             "dispatch, against the hipGraph replay of the timed region")
         if "flash_attn" in summ:
             fa = summ["flash_attn"]
             roof["flash_attn_tflops"] = round(fa["flops"] / (fa["ms"] * 1e-3) / 1e12, 1)

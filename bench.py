@@ -52,9 +52,29 @@ class Recorder:
         self.items = []
         self.group = []          # per item: twin-region id or None
         self.twin = bool(twin)
+        self.floor_ms = 0.0
         self._cur = None
         self._n_groups = 0
         self._ms = None
+
+    def calibrate(self, dev):
+        """Event-pair floor: what a HIP event pair reads around a launch that does (almost) nothing -- the dispatch latency between
+        the first event's completion and the kernel's start, which a graph replay does not pay per node.  Measured on 200 launches
+        of the one-thread saspa_index_add kernel (minimum), subtracted from every recorded duration."""
+        import torch
+
+        from saspa_aug_amd import ops
+        idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        ev = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.index_add(idx, 1)
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        self.floor_ms = min(a.elapsed_time(b) for a, b in ev[20:])
+        return self.floor_ms
 
     def begin_twin(self):
         self._cur = self._n_groups
@@ -80,7 +100,7 @@ class Recorder:
         if self._ms is not None and len(self._ms) == len(self.items):
             return self._ms
         torch.cuda.synchronize()
-        dur = [e0.elapsed_time(e1) for _, _, e0, e1, _ in self.items]
+        dur = [max(e0.elapsed_time(e1) - self.floor_ms, 0.0) for _, _, e0, e1, _ in self.items]
         ms = list(dur)
         if self._n_groups:
             ref = next(e0 for (_, _, e0, _, _), g in zip(self.items, self.group) if g is not None)
@@ -140,7 +160,8 @@ class Recorder:
 
     KERNEL_OF_FAMILY = {1: "gemm_dma_kernel / gemm_kernel (4-wave 128x160 / 128x128 / 128x32 / 64x64 tiles)",
                         2: "gemm_pp_kernel (8-wave 256x320 / 256x256 tile, one workgroup per CU)",
-                        3: "gemm_ws_kernel (12-wave wave-specialised 128x160)", 4: "gemm_as_kernel (A-stationary, K = 320)"}
+                        3: "gemm_ws_kernel (12-wave wave-specialised 128x160)", 4: "gemm_as_kernel (A-stationary, K = 320)",
+                        8: "gemm_f8_kernel (e4m3 W8A8, 128x128x128-byte tiles, v_mfma_scale_f32_16x16x128_f8f6f4)"}
     PROFILE_NAME_OF_FAMILY = {1: ("gemm_dma_kernel", "gemm_kernel"), 2: ("gemm_pp_kernel",), 3: ("gemm_ws_kernel",), 4: ("gemm_as_kernel",)}
 
     @staticmethod
@@ -559,6 +580,7 @@ def run(args):
         # twin=True: the recorded eager evaluation runs the two encoders on two streams with the shared-chip dispatch, like the
         # captured step of the timed region, and charges the paired launches their share of the pair's wall time
         rec, rec1 = Recorder(twin=True), Recorder(twin=True)
+        rec1.floor_ms = rec.calibrate(dev)
         imgs, ids, lat_dev = batches[0]
         ctrl = ops.canny(imgs, 120, 200)
         pipe.generate_batch(ids, neg, ctrl, lat_dev, 1, 7.5, 0.75, latents_on_device=True)   # warm
@@ -671,7 +693,8 @@ def run(args):
         roof["timed_path_check"] = dict(recorded_ms_per_sampling_step=round(step_ms, 3), recorded_fixed_ms_per_batch=round(fixed_ms, 2),
                                         predicted_ms_per_batch=round(pred, 1), measured_ms_per_batch=round(dt / args.steps * 1e3, 1),
                                         predicted_over_measured=round(pred / (dt / args.steps * 1e3), 4),
-                                        twin_regions=len(getattr(rec, "twin_regions", [])),
+                                        twin_regions=len(getattr(rec, "twin_regions", [])), launches_recorded=len(rec.items),
+                                        event_pair_floor_us=round(rec.floor_ms * 1e3, 2),
                                         what="sum of the charged times of every recorded launch (all kinds), eager loop with the production "
                                              "dispatch, against the hipGraph replay of the timed region")
         if "flash_attn" in summ:

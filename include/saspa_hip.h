@@ -443,6 +443,12 @@ typedef struct SaspaGemmF8Params {
   const void* residual; int ldr;
   int act;
   void* out; int ldo;
+  /* ABI 20 (configs[4] breadth: self-attention Q|K|V and the feed-forward OUTPUT projection on fp8 tiles too) */
+  int sa_broadcast;        /* 1: `sa` is ONE fp32 scale for every row (an activation tensor quantised under a tensor-wide scale) */
+  int out_fp8;             /* GEGLU only. 1: `out` receives e4m3 BYTES, out[m][n] = sat(gelu-gated value / *out_scale), ldo in bytes
+                            * (% 16): BasicTransformerBlock.ff.net.0 -> ff.net.2 without a bf16 round trip or a quantisation pass */
+  const float* out_scale;  /* device scalar read by the launch (required with out_fp8); a power of two keeps e4m3 rounding scale-free */
+  float* amax;             /* GEGLU only, optional device scalar: atomic max of |gated value| over the launch (calibration of out_scale) */
 } SaspaGemmF8Params;
 int saspa_gemm_fp8(const SaspaGemmF8Params* p, void* stream);
 int saspa_layernorm_quant_fp8(const void* x, int ldx, void* q, int ldq, float* scale, long long rows, int C,

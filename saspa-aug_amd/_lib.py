@@ -71,6 +71,7 @@ class GemmF8Params(C.Structure):
         ("a", C.c_void_p), ("lda", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("sa", C.c_void_p), ("sw", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int),
         ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int),
+        ("sa_broadcast", C.c_int), ("out_fp8", C.c_int), ("out_scale", C.c_void_p), ("amax", C.c_void_p),      # ABI 20
     ]
 
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(const SaspaGemmF8Params
   for (int i = 0; i < 4; ++i) {
     const int mrow = wm * 64 + i * 16 + frow;
     const int m = bm * BM + mrow;
-    const float sa = m < p.M ? p.sa[m] : 0.f;
+    const float sa = m < p.M ? p.sa[p.sa_broadcast ? 0 : m] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ncol = wn * 64 + j * 16 + fg * 4;
@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(const SaspaGemmF8Params
   bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
   if constexpr (GEGLU) {
     // tile columns [0, 64) are values, [64, 128) their gates (weights.pack_geglu with a 128-column tile)
+    float amax = 0.f;
+    const float inv_os = p.out_fp8 ? 1.0f / *p.out_scale : 1.0f;
     for (int q = tid; q < BM * 8; q += 256) {
       const int row = q >> 3, ch = q & 7;
       const int m = bm * BM + row;
@@ -124,7 +126,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f8_kernel(const SaspaGemmF8Params
       unpack8(*reinterpret_cast<const uint4*>(ct + row * CP + 64 + ch * 8), g);
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] = fast_gelu_mul(a[e], g[e]);
-      *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + bn * 64 + ch * 8) = pack8(a);
+      if (p.amax) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(a[e]));
+      }
+      if (p.out_fp8) {
+        // ABI 20: the feed-forward hidden state leaves as e4m3 under ONE tensor-wide scale (a power of two from a calibration
+        // pass, see SaspaGemmF8Params.out_scale): the output projection reads bytes, no quantisation pass exists.  Saturating.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = fminf(fmaxf(a[e] * inv_os, -448.f), 448.f);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(a[4], a[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(a[6], a[7], w1, true);
+        *reinterpret_cast<int2*>(reinterpret_cast<uint8_t*>(p.out) + (long long)m * p.ldo + bn * 64 + ch * 8) = make_int2(w0, w1);
+      } else {
+        *reinterpret_cast<uint4*>(out + (long long)m * p.ldo + bn * 64 + ch * 8) = pack8(a);
+      }
+    }
+    if (p.amax) {
+      amax = wave_max(amax);
+      // non-negative floats order like their bit patterns: one integer atomic per wave
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax), __float_as_uint(amax));
     }
   } else {
     const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
@@ -233,6 +257,9 @@ extern "C" int saspa_gemm_fp8(const SaspaGemmF8Params* pp, void* stream) {
   if (p.lda < p.K || p.ldw < p.K || p.lda % 16 || p.ldw % 16) return SASPA_EALIGN;
   if (!aligned16(p.a) || !aligned16(p.w) || !aligned16(p.out) || !aligned16(p.sw) || (p.bias && !aligned16(p.bias))) return SASPA_EALIGN;
   if (p.ldo % 8 || p.ldo < (p.act == SASPA_ACT_GEGLU ? p.N / 2 : p.N)) return SASPA_EALIGN;
+  if (p.out_fp8 && (p.act != SASPA_ACT_GEGLU || !p.out_scale)) return SASPA_EINVAL;       // fp8 emission exists in the GEGLU epilogue only
+  if (p.amax && p.act != SASPA_ACT_GEGLU) return SASPA_EINVAL;
+  if (p.out_fp8 && (p.ldo % 16)) return SASPA_EALIGN;                                      // the consumer's DMA reads 16-byte pieces
   if (p.act == SASPA_ACT_GEGLU && p.residual) return SASPA_ERANGE;
   if (p.residual && (p.ldr % 8 || !aligned16(p.residual))) return SASPA_EALIGN;
   if ((long long)p.M * p.lda >= (1ll << 31) || (long long)p.N * p.ldw >= (1ll << 31)) return SASPA_ERANGE;   // 32-bit DMA offsets

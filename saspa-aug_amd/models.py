@@ -168,6 +168,8 @@ class _Net:
         # saspa_gemm_fp8 (bf16 networks only; blocks whose width is not a multiple of 128 stay bf16)
         self.fp8 = bool(fp8) and dtype == torch.bfloat16
         self.fp8_blocks = set()
+        self.fp8_qkv = set()              # blocks whose fused self-attention projection runs on fp8 tiles (round 6)
+        self.fp8_ffout = {}               # block -> calibrated?  (feed-forward output projection on fp8 tiles, round 6)
         self.xattn_blocks = set()         # transformer blocks whose cross-attention half can run as one launch (ops.xattn_block)
         self.pk = _Packed(sd, dev, dtype)
         self.p = self.pk.p
@@ -383,8 +385,14 @@ class _Net:
         return ops.conv(h, p[pfx + ".conv2.w"], p[pfx + ".conv2.b"], kh=3, kw=3, pad=1, residual=sc, gn_unit=self.gn_unit)
 
     def _quantize_block(self, t):
-        """e4m3 copies (per-output-channel scales) of the two projections that read a LayerNorm's output; the GEGLU
-        projection's rows are regrouped for the fp8 kernel's 128-column tiles."""
+        """e4m3 copies (per-output-channel scales) of a transformer block's projections for saspa_gemm_fp8.
+        Round 3: the two projections that read a LayerNorm's output through `saspa_layernorm_quant_fp8` (attn2.to_q, ff.net.0.proj;
+        the GEGLU projection's rows regrouped for the fp8 kernel's 128-column tiles).  Round 6 (SASPA_FP8_BREADTH=all, the
+        default; =ln restores round 3): also the fused self-attention [to_q; to_k; to_v] -- same LayerNorm-quantise pass, the
+        flash kernel reads its V columns row-major -- and the feed-forward OUTPUT projection ff.net.2, whose input leaves the
+        GEGLU epilogue as e4m3 under one calibrated tensor-wide power-of-two scale (`ff.amax` / `ff.scale`, see transformer()):
+        16 of the 18 C^2 multiply-accumulates per token of a block run on fp8 tiles (attn1 / attn2 to_out stay bf16: their input
+        is the attention kernel's output)."""
         sd, p = self.pk.sd, self.p
         wq, sw = W.quantize_fp8(sd[t + ".attn2.to_q.weight"].float() * self.qscaled.get(t, 1.0))   # same fold as the bf16 rows
         p[t + ".attn2.q.w8"], p[t + ".attn2.q.sw"] = wq.to(self.dev), sw.to(self.dev)
@@ -393,6 +401,25 @@ class _Net:
         p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"] = wq.to(self.dev), sw.to(self.dev), _f32(bg, self.dev)
         del p[t + ".attn2.q.w"], p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"]
         self.fp8_blocks.add(t)
+        if os.environ.get("SASPA_FP8_BREADTH", "all") != "all":
+            return
+        c = sd[t + ".norm1.weight"].numel()
+        if (t + ".attn1.qkv.w") in p and rowmajor_v_enabled() and (t + ".attn1.to_q.bias") not in sd:
+            wqkv = torch.cat([sd[t + ".attn1.to_q.weight"].float() * self.qscaled.get(t, 1.0), sd[t + ".attn1.to_k.weight"].float(),
+                              sd[t + ".attn1.to_v.weight"].float()], 0)
+            assert wqkv.shape == (3 * c, c)
+            wq, sw = W.quantize_fp8(wqkv)
+            p[t + ".attn1.qkv.w8"], p[t + ".attn1.qkv.sw"] = wq.to(self.dev), sw.to(self.dev)
+            for k in (".attn1.qkv.w", ".attn1.qk.w", ".attn1.v.w"):
+                p.pop(t + k, None)
+            self.fp8_qkv.add(t)
+        if (4 * c) % 128 == 0:
+            wq, sw = W.quantize_fp8(sd[t + ".ff.net.2.weight"].float())
+            p[t + ".ff.net.2.w8"], p[t + ".ff.net.2.sw"] = wq.to(self.dev), sw.to(self.dev)
+            del p[t + ".ff.net.2.w"]
+            p[t + ".ff.amax"] = torch.zeros(1, device=self.dev, dtype=torch.float32)
+            p[t + ".ff.scale"] = torch.ones(1, device=self.dev, dtype=torch.float32)
+            self.fp8_ffout[t] = False          # -> True once the scale has been calibrated (first execution of the block)
 
     def transformer(self, pfx, x):
         p, g = self.p, self.cfg["groups"]
@@ -409,7 +436,12 @@ class _Net:
             fuse = wqkv is not None and c == 320 and t not in self.fp8_blocks and n % 32 == 0 and \
                 ops.linear_ln_fusable(h, wqkv, n_out=2 * c)
             pre = t in self.qscaled
-            if fuse:
+            if t in self.fp8_qkv:
+                # W8A8 (round 6): LayerNorm + per-token quantisation in one pass, ONE e4m3 projection launch for Q | K | V
+                q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm1.g"], p[t + ".norm1.b"])
+                qkv = ops.linear_fp8(q8, s8, p[t + ".attn1.qkv.w8"], p[t + ".attn1.qkv.sw"])          # [B,N,3C] bf16
+                o = attention_core(qkv[:, :, :c], qkv[:, :, c:2 * c], qkv[:, :, 2 * c:3 * c], heads, n, n, prescaled=pre, v_rowmajor=True)
+            elif fuse:
                 vt = torch.empty((b, c, n), device=h.device, dtype=h.dtype)
                 qk = ops.linear(h, wqkv, None, ln=(p[t + ".norm1.g"], p[t + ".norm1.b"], 1e-5), out_t=vt, n_split=2 * c, rows_per_batch=n)
                 o = attention_core(qk[:, :, :c], qk[:, :, c:], vt, heads, n, n, prescaled=pre)
@@ -432,6 +464,23 @@ class _Net:
                 o = attention_core(q, k, vtc, heads, n, nk, prescaled=pre)
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
                 q8, s8 = ops.layernorm_quant_fp8(h, p[t + ".norm3.g"], p[t + ".norm3.b"])
+                if t in self.fp8_ffout:
+                    # the hidden state leaves the GEGLU epilogue as e4m3 under ONE tensor-wide scale and the output projection
+                    # reads the bytes.  The scale is calibrated the first time the block runs (always an eager launch: a step graph
+                    # is captured after an eager warm-up step): one extra GEGLU launch measures max |value|, the scale becomes the
+                    # power of two >= 16 * max / 448 -- e4m3 is a floating format, a power-of-two scale only shifts exponents, so
+                    # the bytes do not depend on the calibration batch short of overflow (4 binades of head room, saturating)
+                    if not self.fp8_ffout[t]:
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError("fp8 feed-forward scale of %s is not calibrated: run one eager evaluation before capture" % t)
+                        ops.linear_fp8(q8, s8, p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"],
+                                       act=ops.ACT_GEGLU, amax=p[t + ".ff.amax"])
+                        p[t + ".ff.scale"].copy_(ops.fp8_pow2_scale(p[t + ".ff.amax"]))
+                        self.fp8_ffout[t] = True
+                    ff8 = ops.linear_fp8(q8, s8, p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"],
+                                         act=ops.ACT_GEGLU, out_fp8_scale=p[t + ".ff.scale"])
+                    h = ops.linear_fp8(ff8, p[t + ".ff.scale"], p[t + ".ff.net.2.w8"], p[t + ".ff.net.2.sw"], p[t + ".ff.net.2.b"], residual=h)
+                    continue
                 ff = ops.linear_fp8(q8, s8, p[t + ".ff.net.0.proj.w8"], p[t + ".ff.net.0.proj.sw"], p[t + ".ff.net.0.proj.b8"],
                                     act=ops.ACT_GEGLU)
                 h = ops.linear(ff, p[t + ".ff.net.2.w"], p[t + ".ff.net.2.b"], residual=h)

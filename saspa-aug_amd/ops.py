@@ -81,7 +81,8 @@ def _L():
     return lib if _RECORDER is None else _RecordingLib(lib)
 
 
-GEMM_FAMILY_NAMES = {1: "tiled_4wave", 2: "wide_8wave", 3: "wave_specialised", 4: "a_stationary"}
+GEMM_FAMILY_FP8 = 8                  # recorder meta only: launches of saspa_gemm_fp8 (not a SaspaGemmParams.variant)
+GEMM_FAMILY_NAMES = {1: "tiled_4wave", 2: "wide_8wave", 3: "wave_specialised", 4: "a_stationary", 8: "fp8_e4m3"}
 
 
 def _meta_kernel(p, meta):
@@ -799,25 +800,52 @@ def layernorm_quant_fp8(x, gamma, beta, eps=1e-5):
     return q.view(*x.shape[:-1], c), scale
 
 
-def linear_fp8(xq, xscale, wq, wscale, bias=None, *, residual=None, act=ACT_NONE):
-    """e4m3 activations (uint8 [..., K] + per-row scale) @ e4m3 weights (uint8 [N, K] + per-channel scale)^T -> bf16
-    [..., N] (N / 2 with the fused GEGLU): `saspa_gemm_fp8`."""
-    _check_dev(xq, xscale, wq, wscale, bias, residual)
+def linear_fp8(xq, xscale, wq, wscale, bias=None, *, residual=None, act=ACT_NONE, out_fp8_scale=None, amax=None):
+    """e4m3 activations (uint8 [..., K] + per-row scale, or ONE scale for the whole tensor: a 1-element `xscale`) @ e4m3 weights
+    (uint8 [N, K] + per-channel scale)^T -> bf16 [..., N] (N / 2 with the fused GEGLU): `saspa_gemm_fp8`.
+    GEGLU only (ABI 20): `out_fp8_scale` (device fp32 scalar) makes the result e4m3 bytes under that tensor-wide scale -- uint8
+    [..., N / 2], what the feed-forward output projection reads --, `amax` (device fp32 scalar) receives the atomic maximum of the
+    gated values' magnitudes (calibration of that scale)."""
+    _check_dev(xq, xscale, wq, wscale, bias, residual, out_fp8_scale, amax)
     k = xq.shape[-1]
     x2 = xq.reshape(-1, k)
     m, n = x2.shape[0], wq.shape[0]
     nout = n // 2 if act == ACT_GEGLU else n
-    out = torch.empty((m, nout), device=xq.device, dtype=torch.bfloat16)
+    if (out_fp8_scale is not None or amax is not None) and act != ACT_GEGLU:
+        raise ValueError("fp8 emission / amax exist in the GEGLU epilogue only")
+    out = torch.empty((m, nout), device=xq.device, dtype=torch.uint8 if out_fp8_scale is not None else torch.bfloat16)
     r2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
     p = _lib.GemmF8Params()
     p.a, p.lda, p.w, p.ldw = _ptr(x2), x2.stride(0) if m > 1 else k, _ptr(wq), wq.stride(0)
     p.M, p.N, p.K = m, n, k
     p.sa, p.sw, p.bias = _ptr(xscale), _ptr(wscale), _ptr(bias)
+    if xscale.numel() == 1 and m > 1:
+        p.sa_broadcast = 1
+    elif xscale.numel() < m:
+        raise ValueError(f"{xscale.numel()} activation scales for {m} rows")
     p.residual, p.ldr = _ptr(r2), 0 if r2 is None else r2.stride(0)
     p.act, p.out, p.ldo = int(act), _ptr(out), nout
+    if out_fp8_scale is not None:
+        if out_fp8_scale.dtype != torch.float32 or out_fp8_scale.numel() != 1:
+            raise ValueError("out_fp8_scale is one fp32 value on the device")
+        p.out_fp8, p.out_scale = 1, _ptr(out_fp8_scale)
+    if amax is not None:
+        if amax.dtype != torch.float32 or amax.numel() != 1:
+            raise ValueError("amax is one fp32 value on the device")
+        p.amax = _ptr(amax)
     _launch("gemm", 2.0 * m * n * k, lambda: _lib.check(_L().saspa_gemm_fp8(C.byref(p), _stream()), "saspa_gemm_fp8"),
-            (m, n, k, 0, 1, 0, False))
+            (m, n, k, 0, 1, 0, False, residual is not None, nout, GEMM_FAMILY_FP8, 1))
     return out.reshape(*xq.shape[:-1], nout)
+
+
+def fp8_pow2_scale(amax, margin=16.0):
+    """Tensor-wide e4m3 scale from a calibration maximum (device fp32 scalar -> device fp32 scalar, no host sync): the power of two
+    >= margin * amax / 448.  e4m3 is a floating format: a power-of-two scale shifts exponents only, so the quantised values do not
+    depend on the calibration batch as long as nothing overflows (the margin: 4 binades; the conversion saturates beyond) or
+    underflows (values below scale * 2^-9 ~ 1e-4 of the calibration maximum flush to zero)."""
+    a = amax.float().reshape(1)
+    s = torch.exp2(torch.ceil(torch.log2((a * (margin / 448.0)).clamp_min(2.0 ** -60))))
+    return torch.where(a > 0, s, torch.ones_like(s))
 
 
 def geglu(x, out=None):

@@ -63,6 +63,54 @@ def test_gemm_fp8(dev, m, k, n, geglu, res):
     assert (err <= tol).all(), (err.max().item(), ref.abs().max().item())
 
 
+@pytest.mark.parametrize("m,k,n", [(515, 640, 5120), (2048, 1280, 10240)])
+def test_gemm_fp8_geglu_emits_fp8_under_a_tensor_scale(dev, m, k, n):
+    """ABI 20: the GEGLU epilogue of saspa_gemm_fp8 with `amax` (calibration) and `out_fp8` (e4m3 bytes under ONE power-of-two
+    scale).  The bf16-output launch of the same operands is the reference: amax = its largest magnitude (up to the bf16 rounding the
+    reference carries), the dequantised bytes are within half an e4m3 ulp of it, a power-of-two change of the scale leaves the
+    decoded values unchanged (the format is floating: the exponent shifts), a far-too-small scale saturates at +-448 instead of
+    producing NaN bytes."""
+    xq8 = (torch.randn(m, k, generator=torch.Generator().manual_seed(4)).clamp(-3, 3) * 100).to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    sa = (0.5 + torch.rand(m, generator=torch.Generator().manual_seed(5))).to(dev)
+    w, b = W.pack_geglu_tile(_rand(n, k, seed=6, scale=1 / math.sqrt(k)), _rand(n, seed=7), 128)
+    wq, sw = W.quantize_fp8(w)
+    wq, sw, b = wq.to(dev), sw.to(dev), b.to(dev)
+    ref = ops.linear_fp8(xq8, sa, wq, sw, b, act=ops.ACT_GEGLU).float()
+    amax = torch.zeros(1, device=dev)
+    again = ops.linear_fp8(xq8, sa, wq, sw, b, act=ops.ACT_GEGLU, amax=amax).float()
+    assert torch.equal(ref, again)                                         # measuring does not change the bf16 result
+    a = amax.item()
+    assert abs(a - ref.abs().max().item()) <= 2 ** -8 * a
+    scale = ops.fp8_pow2_scale(amax)
+    sv = scale.item()
+    assert math.log2(sv) == round(math.log2(sv)) and 16 * a / 448 <= sv < 32 * a / 448
+    q = ops.linear_fp8(xq8, sa, wq, sw, b, act=ops.ACT_GEGLU, out_fp8_scale=scale)
+    assert q.dtype == torch.uint8 and q.shape == (m, n // 2)
+    deq = q.view(torch.float8_e4m3fn).float() * sv
+    err = (deq - ref).abs()
+    assert (err <= (0.0625 + 2 ** -8) * ref.abs() + sv * 2 ** -9 + 1e-6).all(), err.max().item()
+    q4 = ops.linear_fp8(xq8, sa, wq, sw, b, act=ops.ACT_GEGLU, out_fp8_scale=scale / 4)
+    d4 = q4.view(torch.float8_e4m3fn).float() * (sv / 4)
+    big = ref.abs() > sv * 2 ** -4                                           # away from either scale's subnormal range
+    assert torch.equal(d4[big], deq[big])
+    qs = ops.linear_fp8(xq8, sa, wq, sw, b, act=ops.ACT_GEGLU, out_fp8_scale=scale / 4096)
+    ds = qs.view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(ds).all() and ds.abs().max().item() == 448.0
+    # the output projection that reads the bytes: ONE scale for every row == the same scale spelled out per row
+    w2q, sw2 = W.quantize_fp8(_rand(640, n // 2, seed=9, scale=1 / math.sqrt(n // 2)))
+    r = _rand(m, 640, seed=10).bfloat16().to(dev)
+    o1 = ops.linear_fp8(q, scale, w2q.to(dev), sw2.to(dev), residual=r)
+    o2 = ops.linear_fp8(q, scale.expand(m).contiguous(), w2q.to(dev), sw2.to(dev), residual=r)
+    assert torch.equal(o1, o2)
+
+
+def test_fp8_gemm_refuses_fp8_output_outside_the_geglu_epilogue(dev):
+    x8 = torch.zeros(128, 128, dtype=torch.uint8, device=dev)
+    one = torch.ones(1, device=dev)
+    with pytest.raises(ValueError):
+        ops.linear_fp8(x8, one.expand(128).contiguous(), x8, one.expand(128).contiguous(), out_fp8_scale=one)
+
+
 def test_fp8_linear_quantisation_error_vs_bf16_layer(dev):
     """LayerNorm -> Linear: W8A8 (per-token x per-channel scales) against the fp64 layer, next to the bf16 path's error."""
     m, c, n = 2048, 1280, 1280
@@ -107,10 +155,17 @@ def test_sdxl_pipeline_fp8_vs_oracle_and_bf16(dev):
         pipe = pipe.to(dev, torch.bfloat16)
         if mode == "fp8":
             assert len(pipe.unet.fp8_blocks) > 0 and len(pipe.controlnet.fp8_blocks) > 0
+            # round 6 breadth: the fused self-attention projection and the feed-forward output projection too
+            assert len(pipe.unet.fp8_qkv) == len(pipe.unet.fp8_blocks) and len(pipe.unet.fp8_ffout) == len(pipe.unet.fp8_blocks)
+            assert not any(pipe.unet.fp8_ffout.values())                       # scales not calibrated before the first evaluation
         ids2 = pipe.pad_ids_2(ids1)
         out, x, img = pipe.generate_batch(ids1, None, ctrls, lat, steps, 0.0, 0.75, return_latents=True, prompt_ids_2=ids2)
         out2, _, _ = pipe.generate_batch(ids1, None, ctrls, lat, steps, 0.0, 0.75, return_latents=True, prompt_ids_2=ids2)
         assert torch.equal(out, out2)
+        if mode == "fp8":
+            assert all(pipe.unet.fp8_ffout.values()) and all(pipe.controlnet.fp8_ffout.values())
+            sc = [pipe.unet.p[t + ".ff.scale"].item() for t in pipe.unet.fp8_ffout]
+            assert all(v > 0 and math.log2(v) == round(math.log2(v)) for v in sc)    # calibrated powers of two
         outs[mode] = from_nhwc(x, 4)
     refs = [OP.sdxl_controlnet_pipeline(fam, cfgs, torch.from_numpy(ids1[i:i + 1]), torch.from_numpy(ids2[i:i + 1]), ctrls[i],
                                         lat[i:i + 1].float(), steps, return_latents=True)[1] for i in range(b)]

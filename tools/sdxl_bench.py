@@ -38,7 +38,23 @@ for res, steps in ((512, 2), (1024, 4)):
     torch.cuda.synchronize(); t2 = time.time()
     z = torch.randn((b, res // 8, res // 8, 8), device=dev).to(pipe.vae.dtype)
     pipe.vae.decode(z); torch.cuda.synchronize(); tv = time.time() - t2
+    # share of ONE UNet + ControlNet evaluation's algorithmic FLOPs (implicit GEMMs + attention products) that ran on fp8 tiles: every
+    # recorded launch carries its kernel (bench.Recorder / ops._meta_kernel; family 8 = saspa_gemm_fp8); a generation with 2 x steps
+    # minus one with steps leaves exactly `steps` evaluations (text towers, conditioning embedding, VAE cancel)
+    from bench import Recorder
+
+    def recorded(nsteps):
+        rec = Recorder()
+        ops.set_recorder(rec)
+        pipe.generate_batch(ids, None, ops.canny(imgs, 120, 200), lat, nsteps, 0.0, 0.75)
+        ops.set_recorder(None)
+        torch.cuda.synchronize()
+        f8 = sum(fl for k, fl, _, _, m in rec.items if k == "gemm" and Recorder.kernel_family(k, m) == 8)
+        return f8, sum(fl for k, fl, _, _, m in rec.items if k in ("gemm", "flash_attn"))
+    (f8a, falla), (f8b, fallb) = recorded(steps), recorded(2 * steps)
+    f8, fall = f8b - f8a, fallb - falla
     print(json.dumps({"workload": f"SDXL-Turbo + Canny ControlNet, batch={b} {res}x{res}, {steps} DDIM steps, no CFG, ctrl-scale 0.75",
+                      "fp8_flop_share_of_an_evaluation": round(f8 / fall, 4), "tflop_per_evaluation_per_image": round(fall / steps / b / 1e12, 3),
                       "images_per_s": round(b / dt, 3), "s_per_batch": round(dt, 3), "vae_decode_s_per_batch": round(tv, 3),
                       "vae_dtype": str(pipe.vae.dtype).replace("torch.", ""), "vae_gemm": pipe.vae.f32_gemm, "deterministic": bool(torch.equal(out, out2)),
                       "finite": bool(out.float().isfinite().all()), "dtype": "bf16 + fp8 (e4m3 W8A8) transformer projections" if "--fp8" in sys.argv else "bf16", "data": "synthetic"}), flush=True)

@@ -162,6 +162,16 @@ def _check_dev(*ts):
             raise RuntimeError("saspa_aug_amd ops run on the GPU only (tensor is on %s)" % t.device)
 
 
+def sleep_wait(event, poll_s=0.001):
+    """Wait for a recorded torch.cuda.Event WITHOUT spinning a host core: hipEventSynchronize busy-waits on this stack even for
+    hipEventBlockingSync events (rocr::core::BusyWaitSignal::WaitRelaxed under hip::Event::synchronize -- rocgdb stack of the
+    generation loop's launch thread, profiles/r6_host_thread_stacks.txt), so the host polls hipEventQuery and sleeps in between.
+    1 ms granularity against 20-35 ms sampling steps / 1-2 s batches."""
+    import time
+    while not event.query():
+        time.sleep(poll_s)
+
+
 def h2d(t, device, dtype=None):
     """Host -> device copy that does NOT block the host: through pinned memory, asynchronous in the current stream (a
     pageable-memory copy would wait for everything queued before it -- e.g. the previous batch's whole launch sequence --

@@ -215,15 +215,16 @@ class _StepGraph:
             return self.x
         # Host throttle (round 6): the HIP queue holds about five replays of the ~1 500-node step; once it is full, hipGraphLaunch
         # SPINS on the calling thread until a slot frees -- one host core per rank at 100 % for the whole run
-        # (profiles/r6_config3_full_shard.json: 0.21 CPU-s per image in the launch thread alone).  Keeping at most `depth` replays
-        # outstanding behind BLOCKING events (hipEventBlockingSync: the thread sleeps in the driver) leaves the GPU the same backlog
-        # to chew on (3 replays = 70-100 ms) and gives the core back.  SASPA_REPLAY_DEPTH=0 restores the unthrottled loop.
+        # (profiles/r6_config3_full_shard.json: 0.21 CPU-s per image in the launch thread alone; a replay itself costs the host
+        # 1.4 ms, tools/graph_host_cost.py).  Keeping at most `depth` replays outstanding and SLEEPING until the oldest has finished
+        # (ops.sleep_wait: event query + 1 ms naps -- hipEventSynchronize busy-waits here even with hipEventBlockingSync) leaves
+        # the GPU the same backlog to chew on (3 replays = 70-100 ms) and gives the core back.  SASPA_REPLAY_DEPTH=0 = unthrottled.
         evs = self._replay_events
         for _ in range(self.evals):
             if len(evs) >= depth:
-                evs.pop(0).synchronize()
+                ops.sleep_wait(evs.pop(0))
             self.graph.replay()
-            e = torch.cuda.Event(blocking=True)
+            e = torch.cuda.Event()
             e.record()
             evs.append(e)
         return self.x

@@ -635,8 +635,9 @@ def hip_batch_generator(pipe, s: Settings):
                 c = ctrl.cpu() if ctrl is not None else None
                 sb = [t.cpu() for t in subs] if subs is not None else None
             else:
-                # asynchronous copies into pinned buffers, then ONE wait on a blocking event: the thread sleeps in the driver for the
-                # rest of the batch instead of spinning (round 6: host budget of 8 ranks on a 16-core quota)
+                # asynchronous copies into pinned buffers, then ONE sleeping wait (event query + 1 ms naps, ops.sleep_wait): the thread
+                # gives its core back for the rest of the batch instead of spinning in hipMemcpy / hipEventSynchronize (round 6: host
+                # budget of 8 ranks on a 16-core quota)
                 def d2h(t):
                     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                     h.copy_(t, non_blocking=True)
@@ -644,9 +645,9 @@ def hip_batch_generator(pipe, s: Settings):
                 o, sr = d2h(out), d2h(src)
                 c = d2h(ctrl) if ctrl is not None else None
                 sb = [d2h(t) for t in subs] if subs is not None else None
-                done = torch.cuda.Event(blocking=True)
+                done = torch.cuda.Event()
                 done.record()
-                done.synchronize()
+                ops.sleep_wait(done, 0.002)
         return o.numpy(), (c.numpy() if c is not None else None), sr.numpy(), ([t.numpy() for t in sb] if sb is not None else None)
 
     def run(batch, noises, sources, subjects=None, category=None):

@@ -55,3 +55,25 @@ for (M, N, K, has_res) in shapes:
         except RuntimeError:
             row.append(f"{name}    n/a")
     print(f"M={M:6d} N={N:5d} K={K:5d} res={int(has_res)}: " + " | ".join(row) + "  us", flush=True)
+
+# fused-GEGLU projections (ff.net.0.proj, weights regrouped per output tile; random weights time the same): AUTO against the pinned
+# kernels.  Round 6: re-run after the 8-wave kernel's long-interval loop (+2 ... +8 % per launch) -- does its K >= 1024 gate still hold?
+print("GEGLU projections:")
+for (M, N, K) in [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280), (22528, 5120, 640), (5632, 10240, 1280)]:
+    xs = [torch.randn(M, K, device=dev).to(BF) for _ in range(3)]
+    wt = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
+    bias = torch.randn(N, device=dev)
+    outs = [torch.empty(M, N // 2, device=dev, dtype=BF) for _ in range(3)]
+    i = [0]
+    row = []
+    for (name, variant) in (("auto", 0), ("tiled", 1), ("wide", 2), ("ws", 3), ("as", 4)):
+        def f():
+            j = i[0] % 3
+            i[0] += 1
+            ops.linear(xs[j], wt, bias, act=ops.ACT_GEGLU, out=outs[j], variant=variant)
+        try:
+            us = timeit(f)
+            row.append(f"{name} {us:6.1f} ({2.0 * M * N * K / us / 1e6:5.0f} TF/s)")
+        except (RuntimeError, ValueError):
+            row.append(f"{name}    n/a")
+    print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(row), flush=True)

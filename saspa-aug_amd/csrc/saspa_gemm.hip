@@ -1124,7 +1124,10 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       // long K and at least two waves of 256 x 320 tiles: the wide kernel (116 vs 142 us at (4096, 10240, 1280))
       static const bool wide_g = !(getenv("SASPA_GEMM_WIDE_GEGLU") && atoi(getenv("SASPA_GEMM_WIDE_GEGLU")) == 0);   // A/B knob
-      static const int wide_g_k = getenv("SASPA_GEMM_WIDE_GEGLU_K") ? atoi(getenv("SASPA_GEMM_WIDE_GEGLU_K")) : 1024;
+      // round 6: K >= 640 (was 1 024).  With the long-interval loop the level-1 projection (16384, 5120, 640) runs 117 us on the wide
+      // kernel against 137-139 on the 4-wave tiles (175 vs 198-201 at the 512x704 bucket's 22 528 rows), alone and beside a twin
+      // (pair 238 vs 270-275): tools/pointwise_dispatch_sweep.py, tools/twin_sweep.py -> profiles/r6_pointwise_sweep.txt
+      static const int wide_g_k = getenv("SASPA_GEMM_WIDE_GEGLU_K") ? atoi(getenv("SASPA_GEMM_WIDE_GEGLU_K")) : 640;
       const bool want = p.variant == SASPA_GEMM_WIDE || (wide_g && p.variant == SASPA_GEMM_AUTO && p.K >= wide_g_k &&
                                                          (long long)((p.M + 255) / 256) * (p.N / 320) >= 384);
       if (want && nb == 1 && saspa_gemm_pp_eligible(p)) return saspa_gemm_pp_launch(p, s, 1, 5);
@@ -1151,10 +1154,17 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
       return saspa_gemm_pp_launch(p, s, ksplit, (p.N % 320 == 0 || p.N % 256 != 0) ? 5 : 4);
     }
     if (can && pp_mode >= 4) return saspa_gemm_pp_launch(p, s, ksplit, pp_mode);
-    if (can && pp_mode == 1 && p.variant == SASPA_GEMM_AUTO && p.K >= 960) {
+    // round 6: short K (640 <= K < 960: the level-1 pointwise layers) is admitted where the sweeps of the long-interval loop show
+    // the wide kernel ahead -- beside a twin from a whole round of the half chip on (pairs: (16384, 640, 640) + residual 38 vs 50 us,
+    // (16384, 1920, 640) 84 vs 100), alone only from a whole round of the chip on ((16384, 1920, 640): 50.6 vs 53.9; at 128 tiles the
+    // 4-wave kernel keeps (16384, 640, 640): 25.4 vs 29.7).  SASPA_GEMM_WIDE_KMIN=960 restores the round-5 gate.
+    static const int wide_kmin = getenv("SASPA_GEMM_WIDE_KMIN") ? atoi(getenv("SASPA_GEMM_WIDE_KMIN")) : 640;
+    if (can && pp_mode == 1 && p.variant == SASPA_GEMM_AUTO && p.K >= wide_kmin) {
       const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
-      if (fn) {
-        const long long t = (long long)((p.M + 255) / 256) * (p.N / (64 * fn));
+      const long long t0 = fn ? (long long)((p.M + 255) / 256) * (p.N / (64 * fn)) : 0;
+      const bool short_ok = p.K >= 960 || (ksplit == 1 && !must_split && (p.sharing ? t0 >= kTwinWholeRound : t0 >= 256));
+      if (fn && short_ok) {
+        const long long t = t0;
         static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);   // A/B knob
         // a twin launch of the same shape shares the chip (SaspaGemmParams.sharing): 96+ wide tiles are a whole round of this
         // launch's half, for every K the wide kernel takes -- pair times of tools/twin_sweep.py (profiles/r4_twin_sweep.txt):

@@ -332,9 +332,147 @@ def mode_gpu(n_batches, out_json):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# `hosts`: do N co-resident ranks keep their GPUs fed on the host cores they get?  (VERDICT r5 "next" #4; CPU only.)
+# Every rank is a real process running the real run_aug.main on its own shard of the 13 336-item plan -- planner, noise replay,
+# loader thread (PNG decode of the sources), software pipeline, PNG writer processes, status vector -- with the GPU replaced by
+# a stand-in that costs the host what the MI355X path was MEASURED to cost it (profiles/r6_host_budget.json, gpu arm):
+#   * the launch thread is busy for `enqueue_cpu_s` per batch (graph replays 50 x 1.4 ms + the eager pre / post launches) and
+#     then sleeps until the "GPU" is done (ops.sleep_wait in the product);
+#   * one extra thread per rank burns a full core for the whole run: ROCr's AsyncEventsLoop, which the rocgdb stacks show spinning
+#     in hsaKmtWaitOnMultipleEvents while kernels complete at ~70 k / s;
+#   * a batch of bucket (H, W) takes the measured GPU time of that bucket; images come back as photo-like pixels (smooth content +
+#     sensor-like noise) so that the PNG writers work as hard as on generated pictures.
+# Reported per rank: images/s against the GPU-limited rate, writer backlog, CPU seconds; and the node's total cores in use.
+# ----------------------------------------------------------------------------------------------------------------------
+GPU_BATCH_S = {(512, 512): 1.44, (512, 704): 1.55, (512, 768): 1.70, (512, 832): 1.90, (512, 896): 1.89}   # r6 full shard / budget runs
+
+
+def _photo_like(h, w, k, cache={}):
+    if (h, w, k) not in cache:
+        base = synthetic_image(h, w, 900 + k).astype(np.float32)
+        rs = np.random.RandomState(k)
+        # low-pass structure + fine noise: PNG (zlib level Pillow's default) lands near the cost of generated photographs
+        noise = rs.normal(0, 6.0, (h, w, 3)).astype(np.float32)
+        cache[(h, w, k)] = np.clip(base + noise, 0, 255).astype(np.uint8)
+    return cache[(h, w, k)]
+
+
+def host_rank(rank, world, root, prompts, n_batches, enqueue_cpu_s, spin_thread, out_file):
+    import threading
+
+    import torch
+    torch.set_num_threads(1)
+    s = settings(root, prompts, MAX_BATCHES=n_batches)
+    state = dict(gpu_free_at=0.0, busy=True)
+
+    if spin_thread:
+        import hashlib
+
+        def burn():                                   # a C loop that releases the GIL, like a runtime thread would
+            while state["busy"]:
+                hashlib.pbkdf2_hmac("sha256", b"x", b"y", 20000)
+        threading.Thread(target=burn, daemon=True).start()
+
+    def enqueue(batch, noises, sources, subjects=None, category=None):
+        t_end = time.process_time() + enqueue_cpu_s
+        t0 = time.thread_time()
+        while time.thread_time() - t0 < enqueue_cpu_s:   # the launch thread's own CPU work for this batch
+            pass
+        h, w = batch[0].height, batch[0].width
+        start = max(time.time(), state["gpu_free_at"])
+        state["gpu_free_at"] = start + GPU_BATCH_S.get((h, w), 1.7) * len(batch) / BATCH
+        return (batch, state["gpu_free_at"])
+
+    def finish(handle):
+        batch, t_done = handle
+        while time.time() < t_done:
+            time.sleep(0.002)
+        h, w = batch[0].height, batch[0].width
+        imgs = np.stack([_photo_like(h, w, (it.order + 1) % 24) for it in batch])
+        srcs = np.stack([_photo_like(h, w, it.index % 24) for it in batch])
+        ctrl = (imgs > 128).astype(np.uint8) * 255
+        return imgs, ctrl, srcs, None
+
+    def gen(*a):
+        return finish(enqueue(*a))[:2]
+    gen.enqueue, gen.finish = enqueue, finish
+
+    class World(LocalWorld):
+        def get_rank(self):
+            return rank
+
+        def gather(self, t, gathered, dst=0):          # every rank is its own process here: rank 0 sees its own vector only
+            if gathered is not None:
+                super().gather(t, gathered, dst)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+    t0 = time.time()
+    res = R.main(s, batch_generator=gen, dist=World(world))
+    dt = time.time() - t0
+    state["busy"] = False
+    ru1 = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+    done = [it for it in res["mine"] if it.status == 1]
+    log = res["batch_log"]
+    steady = (sum(c for _, _, c, _ in log[2:]) / (log[-1][3] - log[1][3])) if len(log) > 3 else None
+    gpu_s = sum(GPU_BATCH_S.get((h, w), 1.7) * c / BATCH for h, w, c, _ in log[2:])
+    out = dict(rank=rank, images=len(done), seconds=round(dt, 1), images_per_s_steady=round(steady, 3) if steady else None,
+               gpu_limited_images_per_s=round(sum(c for _, _, c, _ in log[2:]) / gpu_s, 3) if len(log) > 3 else None,
+               png_writer_max_backlog=res["png_max_queue"],
+               cpu_s_main_process=round((ru1[0].ru_utime + ru1[0].ru_stime) - (ru0[0].ru_utime + ru0[0].ru_stime), 1),
+               cpu_s_png_writers=round((ru1[1].ru_utime + ru1[1].ru_stime) - (ru0[1].ru_utime + ru0[1].ru_stime), 1),
+               failed=sum(1 for it in res["mine"] if it.status == -1))
+    json.dump(out, open(out_file, "w"))
+
+
+def mode_hosts(world, n_batches, out_json, cores=None, enqueue_cpu_s=0.15, spin_thread=True):
+    import subprocess
+    tmp = tempfile.mkdtemp(prefix="saspa_c3_")
+    try:
+        root = os.path.join(tmp, "ds", "data")
+        materialise(root)
+        prompts = prompts_file(tmp)
+        ncpu = len(os.sched_getaffinity(0))
+        cores = min(cores or ncpu, ncpu)
+        cpus = sorted(os.sched_getaffinity(0))[:cores]
+        procs = []
+        t0 = time.time()
+        for r in range(world):
+            # separate output trees per rank would hide contention on one directory: all ranks write into ONE tree, as in production
+            cmd = ["taskset", "-c", ",".join(map(str, cpus)), sys.executable, os.path.abspath(__file__), "_host_rank", str(r), str(world), root,
+                   prompts, str(n_batches), str(enqueue_cpu_s), str(int(spin_thread)), os.path.join(tmp, f"rank{r}.json")]
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL if r else None))
+        codes = [p.wait() for p in procs]
+        wall = time.time() - t0
+        ranks = [json.load(open(os.path.join(tmp, f"rank{r}.json"))) for r in range(world) if os.path.exists(os.path.join(tmp, f"rank{r}.json"))]
+        tot_cpu = sum(r["cpu_s_main_process"] + r["cpu_s_png_writers"] for r in ranks)
+        out = dict(
+            what=f"{world} co-resident generation ranks on {cores} host cores (taskset), run_aug.main with a GPU stand-in that costs the host what the "
+                 f"MI355X path was measured to cost (launch thread {enqueue_cpu_s} CPU-s per batch then asleep, "
+                 + ("one runtime thread spinning a full core per rank, " if spin_thread else "") +
+                 f"measured GPU seconds per batch and bucket), {n_batches} batches of {BATCH} per rank on the configs[3] plan; CPU only",
+            exit_codes=codes, wall_s=round(wall, 1), cores=cores, ranks=ranks,
+            cores_in_use_avg=round(tot_cpu / wall, 2),
+            every_rank_keeps_its_gpu_fed=bool(ranks and all(r["images_per_s_steady"] and r["images_per_s_steady"] >= 0.97 * r["gpu_limited_images_per_s"] for r in ranks)),
+            min_rate_vs_gpu_limited=round(min(r["images_per_s_steady"] / r["gpu_limited_images_per_s"] for r in ranks), 4) if ranks else None,
+            max_writer_backlog=max(r["png_writer_max_backlog"] for r in ranks) if ranks else None)
+        print(json.dumps(out, indent=1))
+        if out_json:
+            json.dump(out, open(out_json, "w"), indent=1)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "plan"
-    if mode == "plan":
+    if mode == "_host_rank":
+        a = sys.argv[2:]
+        host_rank(int(a[0]), int(a[1]), a[2], a[3], int(a[4]), float(a[5]), bool(int(a[6])), a[7])
+    elif mode == "hosts":
+        # hosts <world> <batches per rank> [out.json] [cores] [enqueue cpu s per batch] [spin thread 0|1]
+        a = sys.argv[2:]
+        mode_hosts(int(a[0]) if a else 8, int(a[1]) if len(a) > 1 else 24, a[2] if len(a) > 2 else None,
+                   int(a[3]) if len(a) > 3 else None, float(a[4]) if len(a) > 4 else 0.15, bool(int(a[5])) if len(a) > 5 else True)
+    elif mode == "plan":
         mode_plan(sys.argv[2] if len(sys.argv) > 2 else None)
     else:
         mode_gpu(int(sys.argv[2]) if len(sys.argv) > 2 else 44, sys.argv[3] if len(sys.argv) > 3 else None)

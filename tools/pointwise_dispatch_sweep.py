@@ -17,7 +17,9 @@ BF = torch.bfloat16
 shapes = [(65536, 960, 320, False), (65536, 640, 320, False), (65536, 320, 320, True), (65536, 320, 1280, True),
           (16384, 1920, 640, False), (16384, 640, 640, True), (16384, 640, 640, False), (16384, 640, 2560, True), (16384, 640, 1280, True), (16384, 640, 960, True),
           (4096, 3840, 1280, False), (4096, 1280, 1280, True), (4096, 1280, 1280, False), (4096, 1280, 5120, True), (4096, 1280, 2560, True), (4096, 1280, 1920, True),
-          (1024, 1280, 1280, True), (1024, 1280, 2560, True)]
+          (1024, 1280, 1280, True), (1024, 1280, 2560, True),
+          # the 512x704 bucket's levels (round 6)
+          (22528, 1920, 640, False), (22528, 640, 640, True), (22528, 640, 2560, True), (5632, 3840, 1280, False), (5632, 1280, 1280, True)]
 
 
 def timeit(fn, n=20):

@@ -15,7 +15,9 @@ CONVS = [(16, 32, 32, 640, 640), (16, 16, 16, 1280, 1280), (16, 8, 8, 1280, 1280
 LINS = [  # (M, N, K, residual, geglu)
     (16384, 640, 640, True, False), (16384, 1920, 640, False, False), (16384, 5120, 640, False, True), (16384, 640, 2560, True, False),
     (4096, 1280, 1280, True, False), (4096, 3840, 1280, False, False), (4096, 10240, 1280, False, True), (4096, 1280, 5120, True, False),
-    (1024, 1280, 1280, True, False), (1024, 1280, 5120, True, False), (1024, 10240, 1280, False, True), (65536, 320, 1280, True, False)]
+    (1024, 1280, 1280, True, False), (1024, 1280, 5120, True, False), (1024, 10240, 1280, False, True), (65536, 320, 1280, True, False),
+    # the 512x704 bucket's level 1 (round 6)
+    (22528, 640, 640, True, False), (22528, 1920, 640, False, False), (22528, 5120, 640, False, True), (22528, 640, 2560, True, False)]
 s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
 

@@ -376,14 +376,6 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     return out
 
 
-def halo_conv_enabled():
-    """SASPA_HALO=1: ResnetBlock2D's norm -> SiLU -> conv pairs of the large levels run as ONE launch each on saspa_conv3x3_halo
-    (GroupNorm applied to the conv's input tile in LDS).  OFF by default: built, parity-tested (tests/test_conv_halo_gpu.py) and
-    measured in round 5 -- at parity with GroupNorm apply + im2col conv per launch and 1.4 % SLOWER end to end
-    (profiles/r5_halo_conv.txt), so the two-launch path stays the production one."""
-    return os.environ.get("SASPA_HALO", "0") == "1"
-
-
 def _gn_source_stats(x, x2, groups):
     """Epilogue statistics of the producers of x (| x2), as `groupnorm` would use them: (stats0, stats1, unit) or None."""
     def _fresh(t):

@@ -177,47 +177,3 @@ def test_halo_conv_ineligible_shapes_return_none(dev):
     assert ops.conv_gn(x, None, torch.randn(320, 432).to(dev, BF)) is None
     x = torch.randn(1, 16, 16, 64).to(dev, BF)
     assert ops.conv_gn(x, None, torch.randn(96, 576).to(dev, BF)) is None      # N neither a multiple of 320 nor of 256
-
-
-def test_halo_path_in_the_pipeline_matches_the_production_path(dev, monkeypatch):
-    """SASPA_HALO=1 (opt-in): the level-0 resnets of UNet and ControlNet run their norm -> SiLU -> conv pairs on
-    saspa_conv3x3_halo.  Full SD-1.5 width, batch 4, 512x512, bf16 + hipGraph, 3 DDIM steps: the latents stay within the
-    bf16 noise of the two-launch production path (both are ~1.3e-2 rms-rel per evaluation from the oracle,
-    tests/test_production_gpu.py) and the fused launches are really taken."""
-    import numpy as np
-
-    from oracle.canny import generate_canny_array
-    from saspa_aug_amd import config as CFG
-    from saspa_aug_amd.pipeline import StableDiffusionControlNetPipeline
-    from saspa_aug_amd.synthetic import negative_prompt_ids, synthetic_image, synthetic_prompt_ids
-    cfgs = {k: v for k, v in CFG.SD15.items() if k != "safety"}
-    fam = W.synth_family(cfgs, seed=0)
-    b, res, steps = 4, 512, 3
-    vocab = cfgs["text"]["vocab"]
-    ids, neg = synthetic_prompt_ids(b, seed=1, vocab=vocab), negative_prompt_ids(vocab)
-    ctrls = np.stack([generate_canny_array(synthetic_image(res, res, 40 + i), 120, 200) for i in range(b)])
-    lat = torch.randn((b, 4, res // 8, res // 8), generator=torch.Generator().manual_seed(1), dtype=torch.float16)
-    outs = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("SASPA_HALO", flag)
-        pipe = StableDiffusionControlNetPipeline(dict(fam), cfgs).to(dev, torch.bfloat16)
-        has32 = any(k.endswith(".conv1.w32") for k in pipe.unet.p)
-        assert has32 == (flag == "1")
-        calls = []
-        if flag == "1":
-            real = ops.conv_gn
-
-            def spy(*a, **k):
-                r = real(*a, **k)
-                calls.append(r is not None)
-                return r
-            monkeypatch.setattr(ops, "conv_gn", spy)
-        _, x, _ = pipe.generate_batch(ids, neg, ctrls, lat, steps, return_latents=True)
-        outs[flag] = x.float().cpu().clone()
-        if flag == "1":
-            monkeypatch.setattr(ops, "conv_gn", real)
-            assert calls and all(calls), "the level-0 resnets did not take the fused launches"
-        del pipe
-        torch.cuda.empty_cache()
-    d = (outs["1"] - outs["0"]).pow(2).mean().sqrt() / outs["0"].pow(2).mean().sqrt()
-    assert d.item() < 3e-2, d.item()

@@ -1156,13 +1156,15 @@ int dispatch(const SaspaGemmParams& p, hipStream_t s) {
     if (can && pp_mode >= 4) return saspa_gemm_pp_launch(p, s, ksplit, pp_mode);
     // round 6: short K (640 <= K < 960: the level-1 pointwise layers) is admitted where the sweeps of the long-interval loop show
     // the wide kernel ahead -- beside a twin from a whole round of the half chip on (pairs: (16384, 640, 640) + residual 38 vs 50 us,
-    // (16384, 1920, 640) 84 vs 100), alone only from a whole round of the chip on ((16384, 1920, 640): 50.6 vs 53.9; at 128 tiles the
-    // 4-wave kernel keeps (16384, 640, 640): 25.4 vs 29.7).  SASPA_GEMM_WIDE_KMIN=960 restores the round-5 gate.
+    // (16384, 1920, 640) 84 vs 100), alone from 144 tiles on ((16384, 1920, 640): 50.6 vs 53.9; at 128 tiles the 4-wave kernel keeps
+    // (16384, 640, 640): 25.4 vs 29.7).  SASPA_GEMM_WIDE_KMIN=960 restores the round-5 gate.
     static const int wide_kmin = getenv("SASPA_GEMM_WIDE_KMIN") ? atoi(getenv("SASPA_GEMM_WIDE_KMIN")) : 640;
     if (can && pp_mode == 1 && p.variant == SASPA_GEMM_AUTO && p.K >= wide_kmin) {
       const int fn = (p.N % 320 == 0) ? 5 : (p.N % 256 == 0) ? 4 : 0;
       const long long t0 = fn ? (long long)((p.M + 255) / 256) * (p.N / (64 * fn)) : 0;
-      const bool short_ok = p.K >= 960 || (ksplit == 1 && !must_split && (p.sharing ? t0 >= kTwinWholeRound : t0 >= 256));
+      // (alone: from 144 tiles, the un-split threshold below -- (22528, 640, 640) + residual, 176 tiles: 31.9 vs 44.6 us; 128 tiles, the
+      // 512x512 case, stay on the 4-wave kernel: 25.4 vs 29.7)
+      const bool short_ok = p.K >= 960 || (ksplit == 1 && !must_split && (p.sharing ? t0 >= kTwinWholeRound : t0 >= 144));
       if (fn && short_ok) {
         const long long t = t0;
         static const bool model = !(getenv("SASPA_GEMM_KSPLIT_MODEL") && atoi(getenv("SASPA_GEMM_KSPLIT_MODEL")) == 0);   // A/B knob

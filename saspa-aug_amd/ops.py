@@ -162,6 +162,25 @@ def _check_dev(*ts):
             raise RuntimeError("saspa_aug_amd ops run on the GPU only (tensor is on %s)" % t.device)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """THE second stream of a device: one per process and device, shared by every step graph's ControlNet branch and by the
+    shortcut-conv fork of the decoder resnets (round 6).  Each _StepGraph used to take its own stream out of torch's 32-stream
+    pool; a long session that captured two-branch graphs for dozens of pipelines ended in a segmentation fault inside
+    hipGraphLaunch (hip::Graph::UpdateStreams, profiles/r5_graph_replay_segv_backtrace.txt); with one shared stream the full GPU
+    suite runs two-branch graphs everywhere (profiles/r6_forkall_tests.log).  SASPA_SIDE_STREAM=per_graph = the old behaviour."""
+    if os.environ.get("SASPA_SIDE_STREAM", "shared") == "per_graph":
+        return torch.cuda.Stream(device=device)
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def sleep_wait(event, poll_s=0.001):
     """Wait for a recorded torch.cuda.Event WITHOUT spinning a host core: hipEventSynchronize busy-waits on this stack even for
     hipEventBlockingSync events (rocr::core::BusyWaitSignal::WaitRelaxed under hip::Event::synchronize -- rocgdb stack of the

@@ -54,22 +54,7 @@ def replay_queue_depth():
         return 3
 
 
-_SIDE_STREAMS = {}
-
-
-def side_stream(device):
-    """THE second capture stream of a device: one per process and device, shared by every step graph (round 6).  Each
-    _StepGraph used to take its own stream out of torch's 32-stream pool; a long session that captured two-branch graphs for
-    dozens of pipelines ended in a segmentation fault inside hipGraphLaunch (hip::Graph::UpdateStreams,
-    profiles/r5_graph_replay_segv_backtrace.txt).  SASPA_SIDE_STREAM=per_graph restores the old behaviour for A/B."""
-    if os.environ.get("SASPA_SIDE_STREAM", "shared") == "per_graph":
-        return torch.cuda.Stream(device=device)
-    key = torch.device(device).index
-    if key is None:
-        key = torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+side_stream = ops.side_stream          # one capture side stream per process and device (ops.side_stream)
 
 
 class _StepGraph:

@@ -101,12 +101,6 @@ class _Packed:
 # ------------------------------------------------------------------------------------------
 # attention (shared by UNet / ControlNet / VAE / CLIP)
 # ------------------------------------------------------------------------------------------
-def sc_fork_enabled():
-    """SASPA_FORK_SC=1: the shortcut convs of the resnets outside the paired encoder region run on the side stream beside norm1 /
-    conv1 (see _Net.resnet).  A/B knob."""
-    return os.environ.get("SASPA_FORK_SC", "0") == "1"
-
-
 def xattn_enabled():
     """SASPA_XATTN=0: the cross-attention half of the level-0 blocks runs as three launches again (A/B knob)."""
     return os.environ.get("SASPA_XATTN", "1") != "0"
@@ -352,26 +346,13 @@ class _Net:
         # (round 6: the halo-tiled conv with the GroupNorm applied in LDS -- saspa_conv3x3_halo, SASPA_HALO=1 in round 5 -- is no longer
         # reachable from the pipeline: parity-green, -1.4 % end to end, both arms in profiles/EXPERIMENTS.md; the kernel stays a tested
         # library entry point)
-        has_sc = pfx + ".conv_shortcut.w" in p
-        # the 1x1 shortcut conv (MFMA-bound) reads the same input as the GroupNorm apply pass (HBM-bound) and nothing needs it before
-        # conv2: outside the paired encoder region -- i.e. in the UNet decoder, whose 12 resnets all carry a shortcut over [hidden | skip]
-        # -- it runs on the side stream beside norm1 / conv1 (SASPA_FORK_SC=1; captured as one more fork / join pair per resnet).  Same
-        # kernels on the same inputs: bit-identical to the single-stream order.
-        fork_sc = has_sc and sc_fork_enabled() and ops._RECORDER is None and not ops._TWIN[0]
-        sc = side = None
-        if fork_sc:
-            main, side = torch.cuda.current_stream(), ops.side_stream(x.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"], x2=x2)
         h = ops.groupnorm(x, p[pfx + ".norm1.g"], p[pfx + ".norm1.b"], g, eps, SILU, x2=x2)
         # conv1 -> norm2 -> SiLU: conv1's output has no other reader (fuse_gn: one launch for reduce + GroupNorm at the small levels)
         h = ops.conv(h, p[pfx + ".conv1.w"], p[pfx + ".conv1.b"], kh=3, kw=3, pad=1, rowvec=rv, gn_unit=self.gn_unit,
                      fuse_gn=(p[pfx + ".norm2.g"], p[pfx + ".norm2.b"], g, eps, SILU))
-        if fork_sc:
-            main.wait_stream(side)
-            sc.record_stream(main)
-        elif has_sc:
+        # (the 1x1 shortcut conv on the side stream beside norm1 / conv1 -- MFMA-bound next to an HBM-bound pass -- measured +-0.1 % at
+        # 512x512 / 512x704 / 512x768 in round 6, like round 4's finer forks: profiles/r6_sc_fork_ab.txt; not kept)
+        if pfx + ".conv_shortcut.w" in p:
             sc = ops.conv(x, p[pfx + ".conv_shortcut.w"], p[pfx + ".conv_shortcut.b"], x2=x2)
         else:
             assert x2 is None

@@ -159,6 +159,13 @@ typedef struct SaspaGemmParams {
    * ABI 19: a contract, not a hint -- a launch that would end on ONE K slice or on a kernel without slabs (fused GEGLU, N <= 32,
    * the weight-stationary and A-stationary kernels) returns SASPA_ERANGE instead of writing `out` behind the caller's back. */
   int defer_reduce;
+  /* ABI 20, SASPA_F32X3 only.  1: `w` holds the weights PRE-SPLIT: every K-tile of 32 packed-K values of a row (128 bytes, where the fp32
+   * values would sit) is [32 bf16 hi | 32 bf16 lo], hi = bf16(w), lo = bf16(w - hi), in the order the kernel's lanes consume a tile:
+   * 16-byte chunk c (0..3) of either half carries tile positions 4c..4c+3 and 16+4c..16+4c+3 (weights.presplit_x3).  The launch then
+   * splits only the activation operand in registers (half the VALU work of the K loop, which is what bounds the SASPA_F32X3 GEMMs);
+   * same products, same order: bit-identical to the in-kernel split.  Needs the LDS-DMA loader ((c0 + c1) % 32 == 0, c0 % 32 == 0 with a
+   * second source); SASPA_ERANGE otherwise. */
+  int w_split;
 } SaspaGemmParams;
 /* Non-zero if the A-stationary kernel can run the problem (bf16 pointwise layer, K = c0 = 320, N % 64 == 0, at least 192
  * blocks of 256 rows, no row vector / split-K / GroupNorm statistics / batching, alpha = 1, activation none or fused GEGLU,

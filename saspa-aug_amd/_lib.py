@@ -26,6 +26,7 @@ class GemmParams(C.Structure):
         ("variant", C.c_int), ("korder", C.c_int), ("gn_stats", C.c_void_p), ("gn_unit", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("out_t", C.c_void_p), ("ldt", C.c_int),
         ("st", C.c_longlong), ("n_split", C.c_int), ("rows_per_batch", C.c_int), ("sharing", C.c_int), ("defer_reduce", C.c_int),
+        ("w_split", C.c_int),                                                                     # ABI 20
     ]
 
 

@@ -790,7 +790,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSTAGE > 2) ? 1 
       for (int j = 0; j < WN; ++j) {
         const int row = wn * (16 * WN) + j * 16 + frow;
         u32x4 wh, wl;
-        Mma<T>::split(lb[row * 8 + (fg ^ (row & 7))], lb[row * 8 + ((4 + fg) ^ (row & 7))], wh, wl);
+        if (p.w_split) {       // ABI 20: the weights arrive as [hi | lo] per K-tile, chunk fg of either half = this lane's 8 k values
+          wh = lb[row * 8 + (fg ^ (row & 7))];
+          wl = lb[row * 8 + ((4 + fg) ^ (row & 7))];
+        } else {
+          Mma<T>::split(lb[row * 8 + (fg ^ (row & 7))], lb[row * 8 + ((4 + fg) ^ (row & 7))], wh, wl);
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i) Mma<T>::run3(wh, wl, xh[i], xl[i], acc[i][j]);
       }
@@ -1001,6 +1006,7 @@ int launch(const SaspaGemmParams& p, hipStream_t s, int ksplit) {
   const bool fast = (ctot % BK) == 0 && (p.c1 == 0 || (p.c0 % BK) == 0) && !dma_off &&
                     (!p.upsample || (p.pad <= 1 && p.hin < 16000 && p.win < 16000));
   if (p.korder == SASPA_KORDER_CHUNK && !fast) return SASPA_ERANGE;   // only the DMA kernels walk K chunk-major
+  if (p.w_split && (!fast || !is_x3<T>::value)) return SASPA_ERANGE;  // pre-split weights: only the SASPA_F32X3 DMA loop reads them
   if constexpr (NT != 256) {
     // 8-wave tiles exist only as DMA kernels; dispatch() guarantees `fast`
     if (!fast) return SASPA_ERANGE;

@@ -57,6 +57,7 @@ class _Packed:
             pk = W.to_chunk_major(pk, kh * kw, self.dtype)
         t = pk.to(self.dev, self.dtype)
         t.saspa_korder = 1 if chunk else 0          # read by ops.conv -> SaspaGemmParams.korder
+        t.saspa_cin = c0p + c1p                     # padded input channels per tap (VAEDecoder._presplit)
         self.p[name + ".w"] = t
         if name + ".bias" in self.sd:
             self.p[name + ".b"] = _f32(self.sd[name + ".bias"], self.dev)
@@ -642,6 +643,22 @@ class VAEDecoder:
         pk.norm("decoder.conv_norm_out")
         pk.conv("decoder.conv_out")
         pk.sd = None
+        if self.f32_gemm == "x3" and os.environ.get("SASPA_X3_PRESPLIT", "1") != "0":
+            self._presplit()
+
+    def _presplit(self):
+        """SASPA_F32X3 (round 6): the conv weights are stored PRE-SPLIT into their bf16 hi | lo halves (weights.presplit_x3,
+        SaspaGemmParams.w_split): the K loop of those GEMMs is bound by the VALU work of splitting BOTH operands in registers
+        (9 splits of 8 values per 60 MFMAs on a 128 x 160 tile), the weights' half of it is time-invariant.  Same products in the
+        same order -- bit-identical to the in-kernel split.  Layers the LDS-DMA loader cannot take (conv_in: 8 input channels)
+        keep fp32 weights.  SASPA_X3_PRESPLIT=0 turns it off (A/B)."""
+        for k, t in list(self.p.items()):
+            cin = getattr(t, "saspa_cin", 0)           # set by _Packed.conv: only conv weights carry it
+            if not k.endswith(".w") or t.dtype != torch.float32 or cin == 0 or cin % 32 or t.shape[1] % 32:
+                continue
+            t2 = W.presplit_x3(t)
+            t2.saspa_korder, t2.saspa_cin, t2.saspa_wsplit = t.saspa_korder, cin, 1
+            self.p[k] = t2
 
     def _pack_resnet(self, pfx):
         pk = self.pk

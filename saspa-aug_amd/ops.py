@@ -356,6 +356,11 @@ def conv(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=0, upsample=False, x2=Non
     p.nb1 = p.nb2 = 1
     p.variant = int(variant)
     p.korder = int(getattr(w, "saspa_korder", 0)) if korder is None else int(korder)
+    if getattr(w, "saspa_wsplit", 0):
+        # weights.presplit_x3 (ABI 20): [hi | lo] bf16 pairs per K-tile -- only the SASPA_F32X3 loop can read them
+        if p.dtype != _lib.SASPA_F32X3:
+            raise RuntimeError("pre-split (SASPA_F32X3) weights used outside ops.f32_gemm_mode('x3')")
+        p.w_split = 1
     # a level-0 pointwise layer the A-stationary kernel takes on whole rounds (Transformer2DModel.proj_out): that kernel has no
     # statistics epilogue, and A-stationary + the consumer's own statistics pass (27 + 12 us) beats the tiled kernel with the
     # statistics in its epilogue (53 us); SASPA_GEMM_AS_OVER_STATS=0 keeps the statistics

@@ -652,6 +652,24 @@ def to_chunk_major(packed, taps, dtype):
     return packed.view(n, taps, c // bk, bk).permute(0, 2, 1, 3).reshape(n, k).contiguous()
 
 
+def presplit_x3(w):
+    """[N, K] fp32 packed weights (any K order, K % 32 == 0) -> the same [N, K] fp32-typed buffer holding, per K-tile of 32 values
+    (128 bytes), [32 bf16 hi | 32 bf16 lo] with hi = bf16(w), lo = bf16(w - hi) (round to nearest even, what the SASPA_F32X3 loop
+    computes in registers), in the order a lane consumes the tile: 16-byte chunk c of either half = tile positions 4c..4c+3,
+    16+4c..16+4c+3 (lane group c reads fp32 chunks c and 4 + c of the ACTIVATION tile).  SaspaGemmParams.w_split (ABI 20): the
+    K loop then splits the activations only."""
+    n, k = w.shape
+    if k % 32 or w.dtype != torch.float32:
+        raise ValueError("presplit_x3 wants fp32 [N, K] with K % 32 == 0")
+    idx = torch.tensor([q for c in range(4) for q in (list(range(4 * c, 4 * c + 4)) + list(range(16 + 4 * c, 20 + 4 * c)))], device=w.device)
+    t = w.reshape(n, k // 32, 32)[:, :, idx]
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    out = torch.cat([hi, lo], dim=2).reshape(n, 2 * k).contiguous().view(torch.float32)
+    assert out.shape == (n, k)
+    return out
+
+
 def to_chunk32_major(packed, taps=9):
     """[N, taps*C] tap-major -> K = ((chunk32 * taps + tap) * 32 + c_in_chunk): the packing of saspa_conv3x3_halo
     (SASPA_KORDER_CHUNK32: one (chunk32, tap) slot is one half of a 64-deep K-tile)."""

@@ -560,6 +560,16 @@ def test_f32x3_gemm(dev, case):
         with ops.f32_gemm_mode("x3"):
             got = from_nhwc(ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, upsample=up), cout)
         exact = from_nhwc(ops.conv(xd, wd, bias.to(dev), kh=3, kw=3, pad=1, upsample=up), cout)
+        if cin % 32 == 0:
+            # ABI 20: weights pre-split into [hi | lo] bf16 per K-tile (weights.presplit_x3, SaspaGemmParams.w_split): the same
+            # products in the same order as the in-kernel split -> bit-identical; outside the x3 mode the buffer is refused
+            ws = W.presplit_x3(wd)
+            ws.saspa_wsplit = 1
+            with ops.f32_gemm_mode("x3"):
+                got2 = from_nhwc(ops.conv(xd, ws, bias.to(dev), kh=3, kw=3, pad=1, upsample=up), cout)
+            assert torch.equal(got2, got)
+            with pytest.raises(RuntimeError):
+                ops.conv(xd, ws, bias.to(dev), kh=3, kw=3, pad=1, upsample=up)
     scale = ref.abs().max().item()
     e3 = (got.double() - ref).abs().max().item() / scale
     ee = (exact.double() - ref).abs().max().item() / scale

@@ -139,6 +139,26 @@ def test_vae_decode_f32x3(dev):
     assert e["exact"] < 2e-5 and e["x3"] < 2e-4, e
 
 
+def test_vae_decode_f32x3_presplit_weights_are_bit_identical(dev, monkeypatch):
+    """Round 6: the x3 VAE stores its conv weights pre-split into bf16 hi | lo halves (models.VAEDecoder._presplit, ABI 20
+    SaspaGemmParams.w_split) -- the decode equals the in-kernel split (SASPA_X3_PRESPLIT=0) bit for bit, and the pre-split form is
+    really in use (every 3x3 / 1x1 conv with a 32-multiple of input channels; conv_in with its 8 keeps fp32 weights)."""
+    cfg = CFG.SDXL_TURBO["vae"]
+    sd = W.synth_state_dict("vae", cfg, 4)
+    z = to_nhwc(torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(14)), torch.float32, dev, cpad=8)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SASPA_X3_PRESPLIT", flag)
+        vae = models.VAEDecoder(sd, cfg, dev, torch.float32, f32_gemm="x3")
+        n_split = sum(1 for t in vae.p.values() if getattr(t, "saspa_wsplit", 0))
+        assert (n_split > 30) == (flag == "1"), n_split
+        assert not getattr(vae.p["decoder.conv_in.w"], "saspa_wsplit", 0)
+        outs[flag] = vae.decode(z).clone()
+    assert torch.equal(outs["0"], outs["1"])
+    exact = models.VAEDecoder(sd, cfg, dev, torch.float32, f32_gemm="exact")
+    assert not any(getattr(t, "saspa_wsplit", 0) for t in exact.p.values())
+
+
 @pytest.fixture(scope="module")
 def full_sd15_nets():
     cfgs = CFG.SD15

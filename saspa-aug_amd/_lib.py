@@ -151,6 +151,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the gfx950 kernels are not built. Run "
             "`make -C saspa-aug_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
+    # torch FIRST: libsaspa_hip.so needs libamdhip64 and must bind to the HIP runtime torch ships and initialises (torch/lib), the one
+    # that owns the device pointers and streams every entry point is handed.  Loaded before torch, the dynamic loader resolves the
+    # dependency to /opt/rocm's copy and torch then rides on THAT runtime: launches fail with hipErrorNoDevice (100) -- seen in round 6
+    # with `python __graft_entry__.py smoke` (build() loaded the library, then smoke() imported torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     # SASPA_HIP_LIB_LENIENT=1 (only with SASPA_HIP_LIB): same-box A/B against an OLDER build that lacks newer symbols
     lenient = bool(os.environ.get("SASPA_HIP_LIB")) and os.environ.get("SASPA_HIP_LIB_LENIENT") == "1"

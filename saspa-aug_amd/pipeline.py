@@ -458,7 +458,8 @@ class StableDiffusionControlNetPipeline:
         if guidance_scale <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) belongs to the SDXL-Turbo branch (SURVEY a9)")
         dev, dt = self.device, self.dtype
-        ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
+        # (np.array: a writable copy -- arrays that come out of PIL are read-only and torch warns about wrapping those)
+        ctrl = torch.from_numpy(np.array(control_u8)) if not torch.is_tensor(control_u8) else control_u8
         ctrl = ops.h2d(ctrl, dev).contiguous()
         b, hh, ww, _ = ctrl.shape
         mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)
@@ -859,7 +860,8 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         self._need_device()
         cfg = guidance_scale > 1.0                         # diffusers: do_classifier_free_guidance = guidance_scale > 1
         dev, dt = self.device, self.dtype
-        ctrl = torch.as_tensor(np.asarray(control_u8)) if not torch.is_tensor(control_u8) else control_u8
+        # (np.array: a writable copy -- arrays that come out of PIL are read-only and torch warns about wrapping those)
+        ctrl = torch.from_numpy(np.array(control_u8)) if not torch.is_tensor(control_u8) else control_u8
         ctrl = ops.h2d(ctrl, dev).contiguous()
         b, hh, ww, _ = ctrl.shape
         mult = 8 << (len(self.cfgs["unet"]["block_out"]) - 1)

@@ -53,6 +53,67 @@ def test_graph_replay_equals_eager_sd15(dev, dtype, monkeypatch):
         ops.set_recorder(None)
 
 
+def test_replay_throttle_and_clock_probe(dev, monkeypatch):
+    """Round 6 host side: (a) the replay loop with at most 3 step-graph launches outstanding behind sleeping waits
+    (SASPA_REPLAY_DEPTH, the default) produces the same latents as the unthrottled loop; (b) `saspa_clock_probe` measures a
+    plausible shader clock (one sleeping wave: s_memtime against the 100 MHz s_memrealtime); (c) `ops.sleep_wait` returns once
+    the event has completed."""
+    cfgs = CFG.tiny()
+    fam = W.synth_family(cfgs, seed=3)
+    pipe = StableDiffusionControlNetPipeline(fam, cfgs).to(dev, torch.bfloat16)
+    args = _inputs(cfgs, 2, 64, 64, 31)
+    outs = {}
+    for depth in ("3", "0", "1"):
+        monkeypatch.setenv("SASPA_REPLAY_DEPTH", depth)
+        outs[depth] = pipe.generate_batch(*args, 6, return_latents=True)[1].clone()
+    assert torch.equal(outs["3"], outs["0"]) and torch.equal(outs["3"], outs["1"])
+    buf = torch.zeros(2, dtype=torch.int64, device=dev)
+    ops.clock_probe(buf, 250)
+    ev = torch.cuda.Event()
+    ev.record()
+    ops.sleep_wait(ev)
+    assert ev.query()
+    clocks, ticks = (int(v) for v in buf.cpu())
+    mhz = 100.0 * clocks / ticks
+    assert ticks > 0 and 300.0 < mhz < 3500.0, (clocks, ticks, mhz)
+    with pytest.raises(RuntimeError):
+        ops.clock_probe(buf, 0)                                  # SASPA_ERANGE: a probe always terminates (1 .. 100000 windows)
+
+
+def test_twin_recorder_charges_the_paired_region_its_wall_time(dev):
+    """bench.Recorder(twin=True): the eager evaluation runs the two encoders on two streams (shared-chip dispatch) between
+    begin_twin / end_twin, every launch is recorded (norms and element-wise passes too, through ops._RecordingLib), and the launches
+    of a paired region are charged exactly that region's wall time in total."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import Recorder
+    cfgs = CFG.tiny()
+    fam = W.synth_family(cfgs, seed=3)
+    pipe = StableDiffusionControlNetPipeline(fam, cfgs).to(dev, torch.bfloat16)
+    args = _inputs(cfgs, 2, 64, 64, 41)
+    ref = pipe.generate_batch(*args, 2, return_latents=True)[1].clone()
+    rec = Recorder(twin=True)
+    rec.calibrate(dev)
+    ops.set_recorder(rec)
+    try:
+        got = pipe.generate_batch(*args, 2, return_latents=True)[1]
+    finally:
+        ops.set_recorder(None)
+    # same dispatch as the captured step (twin hint on in the paired region): the same sums in the same order
+    assert torch.equal(got, ref)
+    ms = rec.charged_ms()
+    assert len(ms) == len(rec.items) and all(m >= 0 for m in ms)
+    kinds = {k for k, *_ in rec.items}
+    assert {"gemm", "flash_attn", "groupnorm_apply", "layernorm"} <= kinds, kinds
+    assert len(rec.twin_regions) == 2                               # one paired region per evaluation
+    for g, reg in enumerate(rec.twin_regions):
+        charged = sum(m for m, grp in zip(ms, rec.group) if grp == g)
+        assert abs(charged - reg["wall_ms"]) <= 1e-3 * max(reg["wall_ms"], 1e-3) + 2e-3
+    fams = {Recorder.kernel_family(k, m) for k, _, _, _, m in rec.items if k == "gemm"}
+    assert fams <= {0, 1, 2, 3, 4, 8} and fams & {1, 2, 3, 4}
+
+
 def test_graph_replay_equals_eager_sdxl(dev, monkeypatch):
     cfgs = CFG.tiny_xl()
     fam = W.synth_family(cfgs, seed=3)

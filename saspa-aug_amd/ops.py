@@ -47,7 +47,8 @@ def _launch(kind, flops, call, meta=None):
         _IN_LAUNCH[0] = False
 
 
-# library entry points that launch nothing (host-side queries): never recorded
+# library entry points that launch nothing (host-side queries), and the clock probe (a sleeping wave used as a gate / clock
+# sample, not work of the path): never recorded
 _HOST_ONLY = ("eligible", "suggest", "ksplit", "which", "as_auto", "abi_version", "build_arch", "clock_probe")
 
 
@@ -166,8 +167,8 @@ _SIDE_STREAMS = {}
 
 
 def side_stream(device):
-    """THE second stream of a device: one per process and device, shared by every step graph's ControlNet branch and by the
-    shortcut-conv fork of the decoder resnets (round 6).  Each _StepGraph used to take its own stream out of torch's 32-stream
+    """THE second stream of a device: one per process and device, shared by every step graph's ControlNet branch (round 6) and
+    by a twin launch recorder's paired region.  Each _StepGraph used to take its own stream out of torch's 32-stream
     pool; a long session that captured two-branch graphs for dozens of pipelines ended in a segmentation fault inside
     hipGraphLaunch (hip::Graph::UpdateStreams, profiles/r5_graph_replay_segv_backtrace.txt); with one shared stream the full GPU
     suite runs two-branch graphs everywhere (profiles/r6_forkall_tests.log).  SASPA_SIDE_STREAM=per_graph = the old behaviour."""

@@ -47,7 +47,8 @@ def fork_enabled():
 
 
 def replay_queue_depth():
-    """Replays of the step graph the host keeps outstanding before it sleeps on a blocking event (see _StepGraph.run)."""
+    """Replays of the step graph the host keeps outstanding before it sleeps until the oldest has finished (see _StepGraph.run;
+    0 = unthrottled)."""
     try:
         return int(os.environ.get("SASPA_REPLAY_DEPTH", "3"))
     except ValueError:
@@ -89,7 +90,7 @@ class _StepGraph:
         self.tables, self.curs, self.ctx_kv = [], [], []
         self.graph = None
         self.side = None                  # second capture stream of the forked step (fork_enabled)
-        self._replay_events = []          # blocking events of the replays still in the queue (run())
+        self._replay_events = []          # events of the replays still in the queue (run())
 
     def _bind(self):
         """Point the networks at this graph's static state."""

@@ -818,7 +818,7 @@ def _main(s: Settings, ds_utils=None, batch_generator=None, dist=None, pipe=None
 
     import time as _time
     prof = os.environ.get("SASPA_PROFILE_LOOP") == "1"          # per-batch host timings in the log (diagnostics)
-    batch_log = []                                               # (height, width, items, t enqueue returned, t drained)
+    batch_log = []                                               # per drained batch: (height, width, items, time drained)
     if s.MAX_BATCHES > 0:
         batches = batches[:s.MAX_BATCHES]
     for bi, batch in enumerate(batches):

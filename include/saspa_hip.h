@@ -521,6 +521,38 @@ int saspa_xattn_block(const SaspaXattnBlockParams* p, void* stream);
  * power-limited and boxes differ by up to 12 %).  No counterpart in the reference (it reports no clocks). */
 int saspa_clock_probe(unsigned long long* out2, int iters, void* stream);
 
+/* ---- feed-forward half of a level-0 transformer block in one launch (ABI 20) ---------------------------------------------
+ * out = residual + W2 ( v * gelu(g) ) + b2 with [v ; g] = W1 LayerNorm(x) + b1, for C = 320 channels and an inner width F (1 280):
+ * BasicTransformerBlock.norm3 -> ff.net.0 (GEGLU) -> ff.net.2 -> residual add (diffusers attention.py; the reference reaches it
+ * through pipe(), run_aug/run_aug.py:278).  Replaces two launches (LayerNorm + GEGLU projection, output projection + residual)
+ * whose [M, F] hidden state made an HBM round trip.  Operands in the layouts the kernel's MFMA chain consumes (weights.pack_ff_block):
+ *   w1  [2 F][ldw1 >= 320] bf16: per slice t of 32 hidden features rows 64 t .. 64 t + 31 = the VALUE rows of features 32 t .. 32 t + 31
+ *       (ff.net.0.proj.weight rows f), rows 64 t + 32 .. 64 t + 63 = their GATE rows (rows F + f);  b1 [2 F] fp32 in the same order.
+ *   w2f [F / 32][10][2][64][8] bf16: ff.net.2.weight as MFMA A-operand fragments -- fragment (t, nb, s), lane (m, h = lane >> 5),
+ *       element e = W2[32 nb + m][32 t + 16 s + (e & 3) + 8 (e >> 2) + 4 h];  b2 [320] fp32.
+ * M % 128 == 0, F % 32 == 0, pitches % 8 == 0, 16-byte aligned operands, 32-bit byte offsets; ln_gamma / ln_beta NULL = no LayerNorm.
+ * saspa_ff_block_eligible: host-side check of the geometry (1 = can run). */
+typedef struct SaspaFfBlockParams {
+  const void* x;             /* [M][ldx] bf16: the block's hidden states (LayerNorm input) */
+  int ldx;
+  const void* residual;      /* [M][ldr] bf16: added to the result (the reference adds x itself) */
+  int ldr;
+  long long M;
+  int F;                     /* inner width (hidden features after the gate): 4 x 320 */
+  const float* ln_gamma;     /* [320] or NULL */
+  const float* ln_beta;
+  float ln_eps;
+  const void* w1;
+  int ldw1;
+  const float* b1;
+  const void* w2f;
+  const float* b2;
+  void* out;                 /* [M][ldo] bf16 */
+  int ldo;
+} SaspaFfBlockParams;
+int saspa_ff_block(const SaspaFfBlockParams* p, void* stream);
+int saspa_ff_block_eligible(const SaspaFfBlockParams* p);
+
 int saspa_abi_version(void);
 const char* saspa_build_arch(void);
 

@@ -76,6 +76,14 @@ class GemmF8Params(C.Structure):
     ]
 
 
+class FfBlockParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int), ("M", C.c_longlong), ("F", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("w1", C.c_void_p), ("ldw1", C.c_int),
+        ("b1", C.c_void_p), ("w2f", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int),
+    ]
+
+
 class HedFuseParams(C.Structure):
     _fields_ = [
         ("nmaps", C.c_int), ("n", C.c_int), ("H", C.c_int), ("W", C.c_int),
@@ -93,6 +101,8 @@ SYMBOLS = {
     "saspa_gemm_as_eligible": (_I, [C.POINTER(GemmParams)]),
     "saspa_gemm_as_auto": (_I, [C.POINTER(GemmParams)]),
     "saspa_gemm_which": (_I, [C.POINTER(GemmParams)]),
+    "saspa_ff_block": (_I, [C.POINTER(FfBlockParams), _P]),
+    "saspa_ff_block_eligible": (_I, [C.POINTER(FfBlockParams)]),
     "saspa_flash_attn_bf16": (_I, [C.POINTER(AttnParams), _P]),
     "saspa_softmax_rows": (_I, [_I, _P, _LL, _I, _I, _F, _I, _I, _P]),
     "saspa_groupnorm_stats": (_I, [C.POINTER(GroupNormParams), _P]),

@@ -688,6 +688,49 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldo, so, m, n, k, nb1, nb2, alpha=
     return out
 
 
+def _ff_params(x, ln, w1p, b1p, w2f, b2, residual, out):
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c) if x.dim() != 2 else x
+    m = x2.shape[0]
+    r2 = x2 if residual is None else (residual.reshape(-1, c) if residual.dim() != 2 else residual)
+    p = _lib.FfBlockParams()
+    p.x, p.ldx, p.residual, p.ldr, p.M, p.F = _ptr(x2), x2.stride(0), _ptr(r2), r2.stride(0), m, w2f.shape[0] * 32
+    if ln is not None:
+        p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(ln[0]), _ptr(ln[1]), float(ln[2])
+    p.w1, p.ldw1, p.b1, p.w2f, p.b2 = _ptr(w1p), w1p.stride(0), _ptr(b1p), _ptr(w2f), _ptr(b2)
+    if out is not None:
+        o2 = out.reshape(-1, c) if out.dim() != 2 else out
+        p.out, p.ldo = _ptr(o2), o2.stride(0)
+    return p, x2, r2, m, c
+
+
+def ff_block_eligible(x, w1p, w2f):
+    """Can `ff_block` take these tokens (bf16, 320 channels, rows % 128 == 0 ...)?  Host-side, launches nothing."""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.shape[-1] != 320 or w1p.dtype != torch.bfloat16 or w2f.dtype != torch.bfloat16:
+        return False
+    p, x2, _, m, _ = _ff_params(x, None, w1p, w1p, w2f, w1p, None, None)
+    p.out, p.ldo = p.x, p.ldx
+    return bool(_lib.load().saspa_ff_block_eligible(C.byref(p)))
+
+
+def ff_block(x, ln, w1p, b1p, w2f, b2, residual=None, out=None):
+    """The feed-forward half of a level-0 transformer block in one launch (saspa_ff_block, include/saspa_hip.h):
+    out = residual + W2 (v * gelu(g)) + b2, [v ; g] = W1 LayerNorm(x) + b1.  x [..., 320] bf16 (uniform row pitch), ln = (gamma, beta,
+    eps) or None, w1p / b1p / w2f / b2 from weights.pack_ff_block (bf16 / fp32 / bf16 / fp32), residual defaults to x."""
+    _check_dev(x, w1p, b1p, w2f, b2, residual, out)
+    if x.dtype != torch.bfloat16 or w1p.dtype != torch.bfloat16 or w2f.dtype != torch.bfloat16:
+        raise TypeError("ff_block: bf16 activations / weights")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    p, x2, r2, m, c = _ff_params(x, ln, w1p, b1p, w2f, b2, residual, out)
+    f = p.F
+    # algorithmic work: the two projections (2 M C 2F + 2 M F C)
+    flops = 2.0 * m * c * 2 * f + 2.0 * m * f * c
+    _launch("gemm", flops, lambda: _lib.check(_L().saspa_ff_block(C.byref(p), _stream()), "saspa_ff_block"),
+            (m, 3 * f, c, 0, 1, 0, False, True, c))
+    return out
+
+
 def flash_attn(q, k, vt, out, heads, d, nq, nk, scale, causal=False, prescaled=False, v_rowmajor=False):
     """q: [B, nq, >=heads*d] view, k: [B, nk, >=heads*d] view, vt: [B, heads*d, ldvt] (keys
     contiguous), out: [B, nq, >=heads*d] view.  bf16 only.  prescaled: q already carries scale * log2(e)

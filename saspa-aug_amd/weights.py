@@ -652,6 +652,27 @@ def to_chunk_major(packed, taps, dtype):
     return packed.view(n, taps, c // bk, bk).permute(0, 2, 1, 3).reshape(n, k).contiguous()
 
 
+def pack_ff_block(w1, b1, w2, b2):
+    """Operands of `saspa_ff_block` (include/saspa_hip.h) from a GEGLU feed-forward: ff.net.0.proj.weight `w1` [2F, 320] (rows 0..F-1
+    values, F..2F-1 gates: diffusers' `hidden, gate = proj(x).chunk(2, -1)`), its bias `b1` [2F], ff.net.2.weight `w2` [320, F] and
+    bias `b2` [320] -> (w1p [2F, 320] fp32, b1p [2F] fp32, w2f [F/32, 10, 2, 64, 8] fp32, b2 [320] fp32):
+    * w1p / b1p: per slice t of 32 features the 32 value rows followed by their 32 gate rows;
+    * w2f: MFMA A-operand fragments of W2 -- fragment (t, nb, s), lane = m + 32 h, element e = W2[32 nb + m][32 t + 16 s + (e & 3) +
+      8 (e >> 2) + 4 h]: the K order in which the kernel's GEGLU stage leaves its packed accumulator registers."""
+    w1, b1, w2, b2 = w1.float(), b1.float(), w2.float(), b2.float()
+    f = w2.shape[1]
+    if w1.shape != (2 * f, 320) or w2.shape[0] != 320 or f % 32 or b1.numel() != 2 * f or b2.numel() != 320:
+        raise ValueError(f"pack_ff_block: unexpected shapes {tuple(w1.shape)} {tuple(w2.shape)}")
+    t = f // 32
+    w1p = torch.cat([w1[:f].reshape(t, 32, 320), w1[f:].reshape(t, 32, 320)], 1).reshape(2 * f, 320).contiguous()
+    b1p = torch.cat([b1[:f].reshape(t, 32), b1[f:].reshape(t, 32)], 1).reshape(2 * f).contiguous()
+    e = torch.arange(8)
+    fidx = 16 * torch.arange(2)[:, None, None] + 4 * torch.arange(2)[None, :, None] + ((e & 3) + 8 * (e >> 2))[None, None, :]   # [s, h, e]
+    g = w2.reshape(10, 32, t, 32)[:, :, :, fidx]                     # [nb, m, t, s, h, e]
+    w2f = g.permute(2, 0, 3, 4, 1, 5).reshape(t, 10, 2, 64, 8).contiguous()
+    return w1p, b1p, w2f, b2.contiguous()
+
+
 def presplit_x3(w):
     """[N, K] fp32 packed weights (any K order, K % 32 == 0) -> the same [N, K] fp32-typed buffer holding, per K-tile of 32 values
     (128 bytes), [32 bf16 hi | 32 bf16 lo] with hi = bf16(w), lo = bf16(w - hi) (round to nearest even, what the SASPA_F32X3 loop

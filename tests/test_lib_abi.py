@@ -141,6 +141,30 @@ def test_gemm_which_is_a_dry_dispatch():
     assert lib.saspa_gemm_which(None) == -1
 
 
+def test_ff_block_host_side_validation():
+    """saspa_ff_block (ABI 20): null operands, geometry (rows % 128, inner width % 32, pitches) and alignment are refused on the host."""
+    lib = _lib.load()
+    a = (C.c_char * 64)()
+    base = (C.addressof(a) + 15) // 16 * 16
+    p = _lib.FfBlockParams()
+    assert lib.saspa_ff_block(C.byref(p), None) == -1
+    p.x = p.residual = p.out = p.w1 = p.b1 = p.w2f = p.b2 = base
+    p.ldx = p.ldr = p.ldo = p.ldw1 = 320
+    p.M, p.F = 100, 1280
+    assert lib.saspa_ff_block_eligible(C.byref(p)) == 0 and lib.saspa_ff_block(C.byref(p), None) == -3      # rows % 128
+    p.M, p.F = 256, 1000
+    assert lib.saspa_ff_block_eligible(C.byref(p)) == 0                                                      # inner width % 32
+    p.F, p.ldo = 1280, 300
+    assert lib.saspa_ff_block_eligible(C.byref(p)) == 0                                                      # pitch < 320
+    p.ldo = 320
+    assert lib.saspa_ff_block_eligible(C.byref(p)) == 1
+    p.ln_gamma = base
+    assert lib.saspa_ff_block(C.byref(p), None) == -1                                                        # gamma without beta
+    p.ln_beta = base
+    p.w2f = base + 8
+    assert lib.saspa_ff_block(C.byref(p), None) == -2                                                        # alignment
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -134,6 +134,27 @@ __device__ __forceinline__ float fast_gelu_mul(float val, float gate) {
   return val * (0.5f * gate * (1.0f + fast_erf(gate * 0.70710678118654752440f)));
 }
 
+// The same arithmetic on two values at a time: the multiplies / FMAs of the polynomial are written on <2 x float> so that they become
+// v_pk_mul_f32 / v_pk_fma_f32 (two IEEE results per issue slot on gfx950); every element sees exactly the operations of fast_gelu_mul
+// in the same order, so the results are bit-identical.  (The transcendentals and the sign transfer stay per element.)
+typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_pk fast_gelu_mul2(f32x2_pk val, f32x2_pk gate) {
+  const f32x2_pk x = gate * 0.70710678118654752440f;
+  const f32x2_pk ax = __builtin_elementwise_abs(x);
+  const f32x2_pk d = __builtin_elementwise_fma(f32x2_pk{0.3275911f, 0.3275911f}, ax, f32x2_pk{1.0f, 1.0f});
+  const f32x2_pk t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2_pk poly = __builtin_elementwise_fma(f32x2_pk{1.061405429f, 1.061405429f}, t, f32x2_pk{-1.453152027f, -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_pk{1.421413741f, 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_pk{-0.284496736f, -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_pk{0.254829592f, 0.254829592f});
+  poly *= t;
+  const f32x2_pk q = -ax * ax * 1.4426950408889634f;
+  const f32x2_pk e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  const f32x2_pk r = __builtin_elementwise_fma(-poly, e, f32x2_pk{1.0f, 1.0f});
+  const f32x2_pk er = {copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+  return val * (0.5f * gate * (1.0f + er));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

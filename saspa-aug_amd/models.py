@@ -107,6 +107,19 @@ def xattn_enabled():
     return os.environ.get("SASPA_XATTN", "1") != "0"
 
 
+def ff_block_enabled():
+    """The feed-forward half of the level-0 transformer blocks (LayerNorm -> GEGLU projection -> output projection -> residual) runs
+    as ONE launch of saspa_ff_block (+0.3 ... 0.5 % images/s at 512x512, +1.0 ... 1.2 % at 512x704, same box, alternating:
+    profiles/r6_ff_block_e2e_ab.txt).  SASPA_FF_BLOCK=0: the GEGLU launch + the output-projection launch again (A/B knob)."""
+    return os.environ.get("SASPA_FF_BLOCK", "1") != "0"
+
+
+def ff_block_min_rows():
+    """Token rows from which the one-launch feed-forward is taken: its grid is one workgroup per 128 rows, one workgroup per CU at a
+    time -- below a full chip of them (256 x 128 rows) the tiled kernels' smaller tiles fill the CUs better.  SASPA_FF_BLOCK_MIN_ROWS."""
+    return int(os.environ.get("SASPA_FF_BLOCK_MIN_ROWS", "32768"))
+
+
 def project_vt(x, wv, nk):
     """vt[b] = Wv @ x_b^T -> [B, C, ld] with keys contiguous (pad columns zero)."""
     b, n, k = x.shape
@@ -165,6 +178,7 @@ class _Net:
         self.fp8_qkv = set()              # blocks whose fused self-attention projection runs on fp8 tiles (round 6)
         self.fp8_ffout = {}               # block -> calibrated?  (feed-forward output projection on fp8 tiles, round 6)
         self.xattn_blocks = set()         # transformer blocks whose cross-attention half can run as one launch (ops.xattn_block)
+        self.ff_blocks = set()            # transformer blocks whose feed-forward half can run as one launch (ops.ff_block)
         self.pk = _Packed(sd, dev, dtype)
         self.p = self.pk.p
         self.temb_tables = {}
@@ -235,6 +249,14 @@ class _Net:
             else:
                 pk.linear(t + ".ff.net.0.proj")
             pk.linear(t + ".ff.net.2")
+            if packed is not None and c == 320 and not self.fp8 and ff_block_enabled():
+                # level 0: the whole feed-forward as one launch -- W1 per 32-feature slice [values | gates], W2 as the MFMA fragments
+                # stage C consumes (weights.pack_ff_block); the two-launch operands stay (tokens the kernel does not take)
+                fw1, fb1, fw2, fb2 = W.pack_ff_block(pk.sd[t + ".ff.net.0.proj.weight"], pk.sd[t + ".ff.net.0.proj.bias"],
+                                                     pk.sd[t + ".ff.net.2.weight"], pk.sd[t + ".ff.net.2.bias"])
+                self.p[t + ".ffb.w1"], self.p[t + ".ffb.b1"] = fw1.to(self.dev, self.dtype), _f32(fb1, self.dev)
+                self.p[t + ".ffb.w2f"], self.p[t + ".ffb.b2"] = fw2.to(self.dev, self.dtype), _f32(fb2, self.dev)
+                self.ff_blocks.add(t)
             if self.fp8 and pk.sd[t + ".norm2.weight"].numel() % 128 == 0:
                 self._quantize_block(t)
             self.blocks.append(t)
@@ -478,6 +500,10 @@ class _Net:
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
             # (with a ragged last round of row blocks -- 512x704 -- the wave-specialised kernel + LayerNorm is as fast: == 2)
+            if t in self.ff_blocks and b * n >= ff_block_min_rows() and ops.ff_block_eligible(h, p[t + ".ffb.w1"], p[t + ".ffb.w2f"]):
+                h = ops.ff_block(h, (p[t + ".norm3.g"], p[t + ".norm3.b"], 1e-5), p[t + ".ffb.w1"], p[t + ".ffb.b1"], p[t + ".ffb.w2f"],
+                                 p[t + ".ffb.b2"], residual=h)
+                continue
             if fuse and t in self.fused_geglu and ops.linear_ln_fusable(h, p[t + ".ff.net.0.proj.w"], act=ops.ACT_GEGLU) == 2:
                 ff = ops.linear(h, p[t + ".ff.net.0.proj.w"], p[t + ".ff.net.0.proj.b"], act=ops.ACT_GEGLU,
                                 ln=(p[t + ".norm3.g"], p[t + ".norm3.b"], 1e-5))

@@ -40,8 +40,12 @@ def _reference(x, w1, b1, w2, b2, g, be, ln=True):
     return (y + xf).to(BF)
 
 
+@pytest.mark.parametrize("ws", ["0", "1"])
 @pytest.mark.parametrize("m,f,ln", [(256, 1280, True), (1024, 1280, True), (128, 64, True), (384, 1280, False), (4096, 320, True)])
-def test_ff_block_vs_reference(dev, m, f, ln):
+def test_ff_block_vs_reference(dev, m, f, ln, ws, monkeypatch):
+    # ws = "1": the wave-specialised form (SASPA_FF_WS: 8 waves, rows / accumulators split over wave pairs); both forms compute the
+    # same sums in the same order -> compared with each other bit for bit below
+    monkeypatch.setenv("SASPA_FF_WS", ws)
     x = (_rand(m, 320, seed=1) * 1.5 + 0.2).to(BF)
     w1, b1, w2, b2, g, be = _operands(f, 10)
     w1p, b1p, w2f, b2p = W.pack_ff_block(w1, b1, w2, b2)
@@ -53,6 +57,10 @@ def test_ff_block_vs_reference(dev, m, f, ln):
     # bf16 output rounding (2^-8 relative) + the fp32 summation order + rare rounding flips of the bf16 hidden state
     assert err.max().item() <= 2.5e-2 * scale, (err.max().item(), scale)
     assert (err.pow(2).mean().sqrt() / ref.float().pow(2).mean().sqrt()).item() < 4e-3
+    if ws == "1":
+        monkeypatch.setenv("SASPA_FF_WS", "0")
+        four = ops.ff_block(x.to(dev), (g.to(dev), be.to(dev), 1e-5) if ln else None, w1p.to(dev, BF), b1p.to(dev), w2f.to(dev, BF), b2p.to(dev))
+        assert torch.equal(four, out)
 
 
 def test_ff_block_vs_the_two_launches_it_replaces(dev):

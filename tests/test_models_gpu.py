@@ -179,6 +179,46 @@ def test_unet_controlnet_full_width_step(dev, full_sd15_nets, dtype):
     assert max(e) < (1e-5 if dtype == torch.float32 else 3.5e-2), e      # 2x the measured 3.5e-6 / 1.74e-2 (r2)
 
 
+def test_unet_controlnet_ff_block_knob(dev, full_sd15_nets, monkeypatch):
+    """SASPA_FF_BLOCK=1: the feed-forward half of the level-0 transformer blocks runs as one saspa_ff_block launch.  Same UNet +
+    ControlNet evaluation with the knob off and on (full width, 256x256 image: 2048 level-0 token rows): the fused launch is taken by
+    all seven level-0 blocks (2 + 2 encoder, 3 decoder) and the noise prediction moves by bf16 rounding only."""
+    cfgs, fam, _ = full_sd15_nets
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 2, 32, 32
+    x = torch.randn(b, 4, h, w, generator=g)
+    ctx = torch.randn(b, 77, cfgs["unet"]["ctx_dim"], generator=g)
+    cond = torch.rand(b, 3, 8 * h, 8 * w, generator=g)
+    ts = OP.DDIM().set_timesteps(4)
+    outs, calls = {}, []
+    real = ops.ff_block
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "ff_block", counted)
+    monkeypatch.setenv("SASPA_FF_BLOCK_MIN_ROWS", "0")                  # (the default takes the launch from a full chip of row blocks)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SASPA_FF_BLOCK", flag)
+        unet = models.UNet(fam["unet"], cfgs["unet"], dev, torch.bfloat16)
+        cn = models.ControlNet(fam["controlnet"], cfgs["controlnet"], dev, torch.bfloat16)
+        assert (len(unet.ff_blocks), len(cn.ff_blocks)) == ((5, 2) if flag == "1" else (0, 0))
+        for net in (unet, cn):
+            net.prepare_context(ctx.to(dev, torch.bfloat16))
+            net.prepare_timesteps(ts)
+        xd = to_nhwc(x, torch.bfloat16, dev, cpad=8)
+        cemb = cn.cond_embedding(to_nhwc(cond, torch.bfloat16, dev, cpad=8))
+        n0 = len(calls)
+        umid, uskips = unet.encode(xd, 1)
+        s2, m2 = cn.forward(xd, 1, cemb, 0.75, uskips, umid)
+        outs[flag] = from_nhwc(unet.decode(m2, s2, 1), 4).float().cpu()
+        assert len(calls) - n0 == (7 if flag == "1" else 0)
+        del unet, cn
+    e = _relerr(outs["1"], outs["0"])
+    print(f"SASPA_FF_BLOCK on vs off: max-rel difference {e}")
+    assert e < 2e-2, e
+
+
 def _pipeline_case(cfgs, fam, dev, dtype, hh, ww, steps, nimg=1):
     ids = torch.from_numpy(np.random.RandomState(1).randint(0, cfgs["text"]["vocab"] - 2, (nimg, 77)))
     neg = torch.from_numpy(np.random.RandomState(2).randint(0, cfgs["text"]["vocab"] - 2, (1, 77)))

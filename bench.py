@@ -161,13 +161,16 @@ class Recorder:
     KERNEL_OF_FAMILY = {1: "gemm_dma_kernel / gemm_kernel (4-wave 128x160 / 128x128 / 128x32 / 64x64 tiles)",
                         2: "gemm_pp_kernel (8-wave 256x320 / 256x256 tile, one workgroup per CU)",
                         3: "gemm_ws_kernel (12-wave wave-specialised 128x160)", 4: "gemm_as_kernel (A-stationary, K = 320)",
-                        8: "gemm_f8_kernel (e4m3 W8A8, 128x128x128-byte tiles, v_mfma_scale_f32_16x16x128_f8f6f4)"}
-    PROFILE_NAME_OF_FAMILY = {1: ("gemm_dma_kernel", "gemm_kernel"), 2: ("gemm_pp_kernel",), 3: ("gemm_ws_kernel",), 4: ("gemm_as_kernel",)}
+                        8: "gemm_f8_kernel (e4m3 W8A8, 128x128x128-byte tiles, v_mfma_scale_f32_16x16x128_f8f6f4)",
+                        16: "ff_block_ws_kernel (level-0 feed-forward in one launch: LayerNorm + GEGLU projection + output projection)"}
+    PROFILE_NAME_OF_FAMILY = {1: ("gemm_dma_kernel", "gemm_kernel"), 2: ("gemm_pp_kernel",), 3: ("gemm_ws_kernel",), 4: ("gemm_as_kernel",),
+                              16: ("ff_block_ws_kernel",)}
 
     @staticmethod
     def kernel_family(kind, meta):
         """Kernel family of a recorded implicit-GEMM launch: ops._meta_kernel appended (family, K slices) -- the library's own
-        dispatch, executed dry (saspa_gemm_which, ABI 20).  0: launches that do not go through saspa_gemm (xattn block, fp8)."""
+        dispatch, executed dry (saspa_gemm_which, ABI 20); saspa_ff_block names its own (16).  0: the other launches that do not go
+        through saspa_gemm (xattn block)."""
         if kind != "gemm" or meta is None or len(meta) < 11:
             return 0
         return int(meta[9])

@@ -83,7 +83,8 @@ def _L():
 
 
 GEMM_FAMILY_FP8 = 8                  # recorder meta only: launches of saspa_gemm_fp8 (not a SaspaGemmParams.variant)
-GEMM_FAMILY_NAMES = {1: "tiled_4wave", 2: "wide_8wave", 3: "wave_specialised", 4: "a_stationary", 8: "fp8_e4m3"}
+GEMM_FAMILY_FF_BLOCK = 16                 # saspa_ff_block (not a saspa_gemm dispatch: the launch names its family itself)
+GEMM_FAMILY_NAMES = {1: "tiled_4wave", 2: "wide_8wave", 3: "wave_specialised", 4: "a_stationary", 8: "fp8_e4m3", 16: "ff_block"}
 
 
 def _meta_kernel(p, meta):
@@ -727,7 +728,7 @@ def ff_block(x, ln, w1p, b1p, w2f, b2, residual=None, out=None):
     # algorithmic work: the two projections (2 M C 2F + 2 M F C)
     flops = 2.0 * m * c * 2 * f + 2.0 * m * f * c
     _launch("gemm", flops, lambda: _lib.check(_L().saspa_ff_block(C.byref(p), _stream()), "saspa_ff_block"),
-            (m, 3 * f, c, 0, 1, 0, False, True, c))
+            (m, 3 * f, c, 0, 1, 0, False, True, c) + ((GEMM_FAMILY_FF_BLOCK, 1) if _RECORDER is not None else ()))
     return out
 
 

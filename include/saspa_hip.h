@@ -531,6 +531,9 @@ int saspa_clock_probe(unsigned long long* out2, int iters, void* stream);
  *   w2f [F / 32][10][2][64][8] bf16: ff.net.2.weight as MFMA A-operand fragments -- fragment (t, nb, s), lane (m, h = lane >> 5),
  *       element e = W2[32 nb + m][32 t + 16 s + (e & 3) + 8 (e >> 2) + 4 h];  b2 [320] fp32.
  * M % 128 == 0, F % 32 == 0, pitches % 8 == 0, 16-byte aligned operands, 32-bit byte offsets; ln_gamma / ln_beta NULL = no LayerNorm.
+ * Two forms of the same arithmetic (bit-identical results): the wave-specialised one (8 waves: 4 keep the token rows and run LayerNorm /
+ * the first projection / the gate, 4 keep the output accumulators and run the second projection / the epilogue) is the default;
+ * SASPA_FF_WS=0 in the environment (read per launch) selects the four-wave form (slower; kept as a cross-check).
  * saspa_ff_block_eligible: host-side check of the geometry (1 = can run). */
 typedef struct SaspaFfBlockParams {
   const void* x;             /* [M][ldx] bf16: the block's hidden states (LayerNorm input) */

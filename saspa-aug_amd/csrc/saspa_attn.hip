@@ -632,8 +632,14 @@ __global__ __launch_bounds__(256) void flash_attn_v2_kernel(const SaspaAttnParam
 #ifndef SASPA_ATTN_PF
 #define SASPA_ATTN_PF 2
 #endif
-template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0, bool RM = false>
+// R (ring slots): 4 = one workgroup barrier per 64-key step; 6 = ONE BARRIER PER TWO STEPS (round 6): at every even step t, after the
+// barrier, tiles t+3 and t+4 go from the two staging register sets into slots (t+3) % 6 and (t+4) % 6 and tiles t+5 / t+6 are
+// requested.  Behind barrier(t) every wave is in step t or t+1, i.e. reads V(t-1), K(t+1), V(t), K(t+2): four live tiles + two
+// being written = six slots; a tile stored in step t is first read (K(t+3)) in step t+2, behind barrier(t+2).  The eight waves
+// re-align half as often: the step measured 1 717 cycles against ~1 100 of issue work, much of the rest barrier skew.
+template <int KS, int NB, bool ONES, int NW = 8, int ABL = 0, bool RM = false, int R = 4>
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAttnParams p) {
+  static_assert(R == 4 || R == 6, "ring of 4 (barrier per step) or 6 slots (barrier per two steps)");
   // RM: V row-major, read through ds_read_b64_tr_b16 (see lds_read_tr16 at the top of the file)
   // NW waves of 32 queries per workgroup: 8 waves halve the K / V^T bytes every query block pulls through L1 / LDS
   // (the staging is the largest single cost of the loop: tools/attn_ablate.py, profiles/r3_attn_ablation.txt)
@@ -650,7 +656,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
   constexpr int NCH_K = (KT * KCH + NT - 1) / NT;
   constexpr int NCH_V = RM ? (KT * DCH + NT - 1) / NT : (DV * VCH + NT - 1) / NT;
   constexpr float BIAS = 8.0f;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BUF];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[R * BUF];
+  auto slot = [](int t) __attribute__((always_inline)) -> int { return R == 4 ? (t & 3) : (int)((unsigned)t % 6u); };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
       const int key = q / DCH, ch = q - key * DCH;
       if (ch >= D8) {
 #pragma unroll
-        for (int bf = 0; bf < 4; ++bf)
+        for (int bf = 0; bf < R; ++bf)
           *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + key * RROW + ch * 16) = u32x4{(ONES && ch == D8) ? 0x00003F80u : 0u, 0u, 0u, 0u};
       }
     }
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
     if (d >= D) {
       const unsigned fill = (ONES && d == D) ? 0x3F803F80u : 0u;
 #pragma unroll
-      for (int bf = 0; bf < 4; ++bf)
+      for (int bf = 0; bf < R; ++bf)
         *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + d * VROW + kc * 16) = u32x4{fill, fill, fill, fill};
     }
   }
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
 
   // S(t) = K(t) Q - m from ring slot t & 3, with the tail mask
   auto qk_tile = [&](int t, f32x16 (&S)[NKB]) __attribute__((always_inline)) {
-    const unsigned char* ksm = smem + (t & 3) * BUF;
+    const unsigned char* ksm = smem + slot(t) * BUF;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
     }
   };
   auto pv_tile = [&](int t, const unsigned (&P)[NKB][8]) __attribute__((always_inline)) {
-    const unsigned char* vsm = smem + (t & 3) * BUF + K_BYTES;
+    const unsigned char* vsm = smem + slot(t) * BUF + K_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2 * NKB; ++ks) {
       const int kb = ks >> 1, half = ks & 1;
@@ -846,10 +853,19 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
   auto step = [&](auto hp, auto hn, int t, f32x16 (&Sc)[NKB], f32x16 (&Sn)[NKB], const unsigned (&Pp)[NKB][8],
                   unsigned (&Pc)[NKB][8], u32x4 (&kreg)[NCH_K], u32x4 (&vreg)[NCH_V]) __attribute__((always_inline)) {
     constexpr bool has_prev = decltype(hp)::value, has_next = decltype(hn)::value;
-    if (t > 0 && !(ABL & 8)) __syncthreads();        // tile t+1 is in LDS for everyone; everyone is done with tile t-2
-    if (t + 2 < ntiles && !(ABL & 8)) {
-      store_tile((t + 2) * KT, smem + ((t + 2) & 3) * BUF, kreg, vreg);
-      if (t + 4 < ntiles) load_tile((t + 4) * KT, kreg, vreg);
+    if constexpr (R == 4) {
+      if (t > 0 && !(ABL & 8)) __syncthreads();        // tile t+1 is in LDS for everyone; everyone is done with tile t-2
+      if (t + 2 < ntiles && !(ABL & 8)) {
+        store_tile((t + 2) * KT, smem + ((t + 2) & 3) * BUF, kreg, vreg);
+        if (t + 4 < ntiles) load_tile((t + 4) * KT, kreg, vreg);
+      }
+    } else if ((t & 1) == 0 && !(ABL & 8)) {
+      // even steps only (see the template comment): set B carries the odd tiles, set A the even ones
+      if (t > 0) __syncthreads();
+      if (t + 3 < ntiles) store_tile((t + 3) * KT, smem + slot(t + 3) * BUF, kregB, vregB);
+      if (t + 4 < ntiles) store_tile((t + 4) * KT, smem + slot(t + 4) * BUF, kregA, vregA);
+      if (t + 5 < ntiles) load_tile((t + 5) * KT, kregB, vregB);
+      if (t + 6 < ntiles) load_tile((t + 6) * KT, kregA, vregA);
     }
     // only the last tile can hold keys >= nk, and the last step is a peeled one: the steady step stays branch-free
     if constexpr (has_prev && !has_next) mask_tail(t, Sc);
@@ -868,8 +884,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
       // the MFMAs clustered at both ends): per MFMA slot [MFMA i | LDS read of the operand of MFMA i+2 | its share of the
       // 8*NKB exponential units].  MFMA i: PV of tile t-1 for i < NPV (ks = i / NB, nb = i % NB), then QK of tile t+1.
       constexpr int NPV = 2 * NKB * NB, NM = NPV + NKB * KS, NU = 8 * NKB;
-      const unsigned char* vsm = smem + ((t - 1) & 3) * BUF + K_BYTES;
-      const unsigned char* ksm = smem + ((t + 1) & 3) * BUF;
+      const unsigned char* vsm = smem + slot(t - 1) * BUF + K_BYTES;
+      const unsigned char* ksm = smem + slot(t + 1) * BUF;
       auto frag = [&](int i) __attribute__((always_inline)) -> u32x4 {
         if (ABL & 4) return u32x4{(unsigned)i, 0x3f803f80u, (unsigned)lane, 0x3f803f80u};
         if (i < NPV) {
@@ -958,6 +974,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
   if (ntiles > 2) load_tile(2 * KT, kregA, vregA);     // set A: even tiles (stored by the even steps)
   if (ntiles > 1) store_tile(KT, smem + BUF, kregB, vregB);
   if (ntiles > 3) load_tile(3 * KT, kregB, vregB);     // set B: odd tiles
+  if constexpr (R == 6) {                              // tile 2 too: step 1 reads K(2) without a barrier in between
+    if (ntiles > 2) store_tile(2 * KT, smem + 2 * BUF, kregA, vregA);
+    if (ntiles > 4) load_tile(4 * KT, kregA, vregA);
+  }
   __syncthreads();
   f32x16 S0[NKB], S1[NKB];
   unsigned P0[NKB][8], P1[NKB][8];
@@ -1072,6 +1092,18 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
 #undef SASPA_V3A
           }
 #endif
+          // six ring slots / one barrier per two steps: measured (tools/attn_bench.py, ring4 / rm4 columns, profiles/r6_attn_ring.txt)
+          // -0.5 % at (16, 8, 4096, 4096, 40) and -1.5 % at 5 632 keys on the V^T path with the ones row, but +3.7 % at d = 64 without
+          // the ones row and +7.7 % on the row-major-V path (236 against 202 registers) -- the barrier is not what the step waits
+          // for.  Taken where it wins; SASPA_ATTN_RING=4: the four-slot ring everywhere (A/B knob, read per launch)
+          const char* re = getenv("SASPA_ATTN_RING");
+          if constexpr (KS == 3 && NB == 2) {
+            if (!rm && p.D < 32 * NB && !(re && atoi(re) == 4)) {
+              hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8, 0, false, 6>), grid8, dim3(512), 0, s, p);
+              SASPA_CHECK_LAUNCH();
+              return 0;
+            }
+          }
           if (rm) {
             if (p.D < 32 * NB) hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, true, 8, 0, true>), grid8, dim3(512), 0, s, p);
             else hipLaunchKernelGGL((flash_attn_v3_kernel<KS, NB, false, 8, 0, true>), grid8, dim3(512), 0, s, p);

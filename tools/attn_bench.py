@@ -3,7 +3,8 @@ SD-1.5 level 0/1/2 self- and cross-attention at CFG batch 16; SDXL levels 1/2 (h
 Columns: v1 = plain queries (scale applied per score); pre0 / pre1 / pre2 = prescaled queries (SASPA_ATTN_QPRESCALED)
 through the v1 loop / the v2 loop with one LDS buffer / the v2 loop with two buffers and one barrier per tile
 (SASPA_ATTN_MODE = 0 / 1 / 2); pre4 = the software-pipelined v3 loop, 8 waves per workgroup (mode 4); auto = the shipped dispatch rule;
-rm = auto with V ROW-MAJOR (SASPA_ATTN_V_ROWMAJOR: the V columns of a fused Q | K | V buffer, transposed LDS reads).  usage: python tools/attn_bench.py [quick] [512x704]"""
+rm = auto with V ROW-MAJOR (SASPA_ATTN_V_ROWMAJOR: the V columns of a fused Q | K | V buffer, transposed LDS reads); ring4 / rm4 = auto / rm
+with SASPA_ATTN_RING=4 (v3 on its four-slot ring, one barrier per 64-key step, instead of six slots and one barrier per two steps).  usage: python tools/attn_bench.py [quick] [512x704]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
@@ -28,13 +29,17 @@ for (B, H, NQ, NK, D) in shapes:
     vrm = qkv[:, :, 2 * C:]
     vt.copy_(vrm.transpose(1, 2)[:, :, :NK]) if vt.shape[2] == NK else vt[:, :, :NK].copy_(vrm.transpose(1, 2))
     arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre2", qs, True, "2"), ("pre4", qs, True, "4"), ("auto", qs, True, ""),
-            ("rm", qs, True, "rm")]
+            ("ring4", qs, True, "ring4"), ("rm", qs, True, "rm"), ("rm4", qs, True, "rm4")]
     best = {a[0]: [] for a in arms}
     ref = None
     for rnd in range(ROUNDS + 1):
         for name, qq, pre, mode in arms:
-            rm = mode == "rm"
-            if mode and not rm:
+            rm = mode in ("rm", "rm4")
+            if mode in ("ring4", "rm4"):                      # the four-slot ring / one barrier per step (round 5's loop)
+                os.environ["SASPA_ATTN_RING"] = "4"
+            else:
+                os.environ.pop("SASPA_ATTN_RING", None)
+            if mode and mode.isdigit():
                 os.environ["SASPA_ATTN_MODE"] = mode
             else:
                 os.environ.pop("SASPA_ATTN_MODE", None)
@@ -51,6 +56,7 @@ for (B, H, NQ, NK, D) in shapes:
                 err = (out.float() - ref).abs().max().item()
                 print(f"   {name}: max |out - v1| = {err:.3e}", flush=True)
     os.environ.pop("SASPA_ATTN_MODE", None)
+    os.environ.pop("SASPA_ATTN_RING", None)
     fl = 4.0 * B * H * NQ * NK * D
     line = "  ".join(f"{n} {sorted(v)[len(v) // 2]:8.1f} us {fl / sorted(v)[len(v) // 2] / 1e6:6.1f} TF/s" for n, v in best.items())
     print(f"B={B} H={H} nq={NQ} nk={NK} d={D}: {line}", flush=True)

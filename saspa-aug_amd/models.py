@@ -114,10 +114,20 @@ def ff_block_enabled():
     return os.environ.get("SASPA_FF_BLOCK", "1") != "0"
 
 
-def ff_block_min_rows():
-    """Token rows from which the one-launch feed-forward is taken: its grid is one workgroup per 128 rows, one workgroup per CU at a
-    time -- below a full chip of them (256 x 128 rows) the tiled kernels' smaller tiles fill the CUs better.  SASPA_FF_BLOCK_MIN_ROWS."""
-    return int(os.environ.get("SASPA_FF_BLOCK_MIN_ROWS", "32768"))
+def ff_block_takes(rows):
+    """Is the one-launch feed-forward the faster form for this many token rows?  Its grid is one workgroup per 128 rows and one workgroup
+    per CU at a time, so its time goes in steps of whole rounds of 256 workgroups (tools/ff_bench.py m=...: 24 576 rows 88 vs 108 us for
+    the two launches, 32 768: 100 vs 135, 65 536: 189 vs 204, 90 112: 274 vs 315; but 16 384: 86 vs 77 and 49 152 -- one and a half
+    rounds -- 176 vs 167): taken from 192 workgroups when they fill their last round to 80 %.  SASPA_FF_BLOCK_MIN_ROWS=<n> replaces the
+    rule by rows >= n (tests: 0 = every size the kernel can run)."""
+    mr = os.environ.get("SASPA_FF_BLOCK_MIN_ROWS")
+    if mr is not None:
+        return rows >= int(mr)
+    wgs = rows // 128
+    if wgs < 192:
+        return False
+    rounds = -(-wgs // 256)
+    return wgs <= 256 or wgs >= 0.8 * rounds * 256
 
 
 def project_vt(x, wv, nk):
@@ -500,7 +510,7 @@ class _Net:
                 h = ops.linear(o, p[t + ".attn2.o.w"], p[t + ".attn2.o.b"], residual=h)
             # GEGLU feed-forward
             # (with a ragged last round of row blocks -- 512x704 -- the wave-specialised kernel + LayerNorm is as fast: == 2)
-            if t in self.ff_blocks and b * n >= ff_block_min_rows() and ops.ff_block_eligible(h, p[t + ".ffb.w1"], p[t + ".ffb.w2f"]):
+            if t in self.ff_blocks and ff_block_takes(b * n) and ops.ff_block_eligible(h, p[t + ".ffb.w1"], p[t + ".ffb.w2f"]):
                 h = ops.ff_block(h, (p[t + ".norm3.g"], p[t + ".norm3.b"], 1e-5), p[t + ".ffb.w1"], p[t + ".ffb.b1"], p[t + ".ffb.w2f"],
                                  p[t + ".ffb.b2"], residual=h)
                 continue

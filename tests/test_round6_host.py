@@ -148,3 +148,17 @@ def test_recorder_twin_charging_arithmetic():
     assert abs(ms[0] - 1.0) < 1e-9 and abs(ms[3] - 0.2) < 1e-9
     assert abs((ms[1] + ms[2]) - 2.01) < 1e-9 and abs(ms[1] / ms[2] - 2.0) < 1e-9
     assert rec.twin_regions == [dict(launches=2, wall_ms=2.01, sum_of_durations_ms=3.0)]
+
+
+def test_ff_block_takes_whole_rounds(monkeypatch):
+    """models.ff_block_takes: the one-launch feed-forward is taken when its 128-row workgroups fill their last round of 256 CUs
+    (tools/ff_bench.py m=...: wins at 24 576 / 32 768 / 65 536 / 90 112 / 98 304 rows, loses at 16 384 and at 49 152 = 1.5 rounds)."""
+    from saspa_aug_amd import models
+    monkeypatch.delenv("SASPA_FF_BLOCK_MIN_ROWS", raising=False)
+    takes = {rows: models.ff_block_takes(rows) for rows in (8192, 16384, 24576, 32768, 49152, 65536, 90112, 98304, 106496, 114688)}
+    assert takes == {8192: False, 16384: False, 24576: True, 32768: True, 49152: False, 65536: True, 90112: True, 98304: True,
+                     106496: True, 114688: True}, takes
+    monkeypatch.setenv("SASPA_FF_BLOCK_MIN_ROWS", "0")
+    assert models.ff_block_takes(128) and models.ff_block_takes(49152)
+    monkeypatch.setenv("SASPA_FF_BLOCK_MIN_ROWS", "70000")
+    assert not models.ff_block_takes(65536) and models.ff_block_takes(90112)

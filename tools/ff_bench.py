@@ -14,7 +14,8 @@ w1p, w2f = w1p.to(BF), w2f.to(BF)
 wg, bg = W.pack_geglu(w1, b1); wg, bg = wg.to(dev, BF), bg.to(dev)
 w2d, b2d = w2.to(BF).to(dev), b2.to(dev)
 ABL = [int(a) for a in sys.argv[1:] if a.isdigit()]          # e.g. `python tools/ff_bench.py 1 2 4 8 16 31`: time the fused kernel under each ablation too
-for m in (65536, 90112, 98304) if not ABL else (65536,):
+MS = [int(a[2:]) for a in sys.argv[1:] if a.startswith('m=')]           # e.g. m=32768 m=16384: other row counts
+for m in (MS or (65536, 90112, 98304)) if not ABL else (65536,):
     xs = [torch.randn(m, 320, device=dev).to(BF) for _ in range(3)]
     outs = [torch.empty(m, 320, device=dev, dtype=BF) for _ in range(3)]
     i = [0]

@@ -162,3 +162,35 @@ def test_ff_block_takes_whole_rounds(monkeypatch):
     assert models.ff_block_takes(128) and models.ff_block_takes(49152)
     monkeypatch.setenv("SASPA_FF_BLOCK_MIN_ROWS", "70000")
     assert not models.ff_block_takes(65536) and models.ff_block_takes(90112)
+
+
+def test_noise_replay_skips_other_ranks_items_bit_exactly(monkeypatch):
+    """run_aug.noise_for_items advances the CPU generator past the items of other ranks with byte draws instead of drawing their noise
+    (rank 7 spent 10.5 s replaying 11 669 items).  The skip is self-checked (`_noise_skip_is_exact`) and must give,
+    for every rank, exactly the tensors of the sequential stream -- one and two draws per item, fp16 and fp32, mixed bucket sizes."""
+    import torch
+    from saspa_aug_amd import run_aug as R
+    sizes = [(512, 512), (512, 704), (512, 768), (576, 512), (512, 896)]
+    items = [R.WorkItem(k, k, "", "", 0, "", "", sizes[k % 5][0], sizes[(k * 7) % 5][1]) for k in range(41)]
+    items[4].skip = items[17].skip = True
+    for dtype in (torch.float16, torch.float32):
+        assert R._noise_skip_is_exact(dtype)                      # holds on this torch: the fast path is the one under test
+        for draws in (1, 2):
+            g = torch.manual_seed(7)
+            ref = {it.order: torch.cat([torch.randn((1, 4, it.height // 8, it.width // 8), generator=g, dtype=dtype) for _ in range(draws)])
+                   for it in items if not it.skip}
+            for sh in R.shard_items(items, 8):
+                monkeypatch.setenv("SASPA_NOISE_SKIP", "1")
+                fast = R.noise_for_items(items, sh, 7, dtype, draws)
+                monkeypatch.setenv("SASPA_NOISE_SKIP", "0")
+                slow = R.noise_for_items(items, sh, 7, dtype, draws)
+                assert set(fast) == set(slow) == {it.order for it in sh}
+                for k in fast:
+                    assert torch.equal(fast[k], ref[k]) and torch.equal(slow[k], ref[k])
+    # a tensor whose element count is not a multiple of 16 is drawn, not skipped (torch's scalar tail path consumes differently)
+    odd = [R.WorkItem(k, k, "", "", 0, "", "", 24, 40) for k in range(6)]          # 4 * 3 * 5 = 60 elements
+    g = torch.manual_seed(3)
+    ref = [torch.randn((1, 4, 3, 5), generator=g, dtype=torch.float32) for _ in range(6)]
+    monkeypatch.setenv("SASPA_NOISE_SKIP", "1")
+    got = R.noise_for_items(odd, odd[4:], 3, torch.float32)
+    assert torch.equal(got[4], ref[4]) and torch.equal(got[5], ref[5])

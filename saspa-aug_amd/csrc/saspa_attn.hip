@@ -1044,6 +1044,336 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_v3_kernel(const SaspaAt
   }
 }
 
+// ---- v4 (round 6): v3's pipeline with SIXTY-FOUR queries per wave and 32-key half steps ------------------------------------
+// v3's ablations add up linearly -- removing the LDS fragment reads saves 89 us of 508, the staging (global -> LDS, barriers) 126 --
+// because an in-order wave pays for everything it issues.  Both are per-QUERY-BLOCK costs: a K or V^T fragment read from LDS feeds ONE
+// MFMA (32 queries), a staged tile serves 256 queries.  Here a wave owns two query blocks (q0 + r and q0 + 32 + r on lane r), so every
+// fragment feeds TWO MFMAs and a workgroup of eight waves shares each staged tile among 512 queries; a step covers 32 keys (one key
+// block) so that S / P of two query blocks are the registers v3 spends on two key blocks of one:
+//     matrix pipe:  O[qb] += V(ht-1) P[qb](ht-1)  (2 NB fragments x 2)   and   S[qb](ht+1) = K(ht+1) Q[qb]  (KS fragments x 2)
+//     VALU:         P[qb](ht) = exp2(S[qb](ht)), packed, OR-checked
+// 14 MFMAs and 32 exponentials per step as in v3, but 7 LDS fragment reads instead of 14, one barrier per TWO steps (tiles stay 64 keys)
+// and half the staging per query.  The registers come from two places: one staging set instead of two (a tile requested at its
+// predecessor's store has the same two steps of flight), and NO accumulator-init vector for the reference level -- the level rides
+// in the head dimension's padding: K's first pad element is 1, Q's is -m (bf16-exact, per query block), so S = K Q - m leaves the
+// MFMA with a literal-zero C operand.  That needs D < 16 KS (d = 40: dims 40 .. 47 are padding) and the ones row of V^T (D < 32 NB).
+template <int KS, int NB, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_v4_kernel(const SaspaAttnParams p) {
+  constexpr int NT = 64 * NW;
+  constexpr int KT = 64, VCH = KT / 8;
+  constexpr int KSLOTS = (2 * KS) | 1;
+  constexpr int KCH = 2 * KS;
+  constexpr int DV = NB * 32;
+  constexpr int VROW = KT * 2 + 16;
+  constexpr int K_BYTES = KT * KSLOTS * 16;
+  constexpr int V_BYTES = DV * VROW;
+  constexpr int BUF = K_BYTES + V_BYTES;
+  constexpr int NCH_K = (KT * KCH + NT - 1) / NT;
+  constexpr int NCH_V = (DV * VCH + NT - 1) / NT;
+  constexpr float BIAS = 8.0f;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int gx = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int grp = lin / (8 * gx), rr = lin - grp * 8 * gx;
+  const int gsz = min(8, nbh - grp * 8);
+  const int bh = grp * 8 + rr % gsz, xq = rr / gsz;
+  const int head = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
+  constexpr int D = 16 * KS - 8, D8 = D >> 3;          // exactly one pad chunk: d = 40 for KS = 3 (the launcher checks p.D)
+  constexpr int sp = KS - 1, hp = 1;                   // the first pad element of the head dimension: fragment sp, lane half hp
+  const int q0 = xq * (64 * NW) + wave * 64;
+
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + head * D;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + head * D;
+  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.vt) + b * p.svb + (long long)head * D * p.ldvt;
+  bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + head * D;
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 qf[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int d = 16 * s + 8 * h, qi = q0 + 32 * qb + r;
+      qf[qb][s] = (qi < p.nq && d < D) ? *reinterpret_cast<const u32x4*>(Q + (long long)qi * p.ldq + d) : zero4;
+    }
+
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kp), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VT), (short)0, 0x7fffffff, 0x00020000);
+  constexpr unsigned kInv = 0x80000000u;
+  unsigned koff[NCH_K], voff[NCH_V];
+  int k_key[NCH_K], k_lds[NCH_K], v_lds[NCH_V], v_kc[NCH_V];
+  bool k_one[NCH_K];
+#pragma unroll
+  for (int i = 0; i < NCH_K; ++i) {
+    const int q = tid + NT * i;
+    const int key = q / KCH, ch = q - key * KCH;
+    k_key[i] = key;
+    k_lds[i] = (q < KT * KCH) ? (key * KSLOTS + ch) * 16 : -1;
+    koff[i] = (q < KT * KCH && ch < D8) ? (unsigned)(key * p.ldk * 2 + ch * 16) : kInv;
+    k_one[i] = ch == D8;                               // the chunk whose first element is the constant 1 that multiplies Q's -m
+  }
+#pragma unroll
+  for (int i = 0; i < NCH_V; ++i) {
+    const int q = tid + NT * i;
+    const int d = q / VCH, kc = q - d * VCH;
+    v_kc[i] = kc;
+    v_lds[i] = (q < DV * VCH && d < D) ? d * VROW + (kc >> 1) * 32 + (kc & 1) * 8 : -1;   // key permutation: see v2
+    voff[i] = (q < DV * VCH && d < D) ? (unsigned)(d * p.ldvt * 2 + kc * 16) : kInv;
+  }
+  for (int q = tid; q < DV * VCH; q += NT) {
+    const int d = q / VCH, kc = q - d * VCH;
+    if (d >= D) {
+      const unsigned fill = d == D ? 0x3F803F80u : 0u;   // the ones row: O^T row D accumulates the softmax denominator
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf)
+        *reinterpret_cast<u32x4*>(smem + bf * BUF + K_BYTES + d * VROW + kc * 16) = u32x4{fill, fill, fill, fill};
+    }
+  }
+  u32x4 kreg[NCH_K], vreg[NCH_V];                        // ONE staging set: tile t+3 is requested when tile t+2 is stored
+  auto load_tile = [&](int key0) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    const unsigned sk = (unsigned)(key0 * p.ldk * 2), sv = (unsigned)(key0 * 2);
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i) {
+      unsigned o = koff[i];
+      if (tail && key0 + k_key[i] >= p.nk) o = kInv;
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)o, (int)sk, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      unsigned o = voff[i];
+      if (tail && key0 + v_kc[i] * 8 >= p.nk) o = kInv;
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, (int)o, (int)sv, 0));
+    }
+  };
+  auto store_tile = [&](int key0, unsigned char* buf) __attribute__((always_inline)) {
+    const bool tail = key0 + KT > p.nk;
+    unsigned char* ksm = buf;
+    unsigned char* vsm = buf + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH_K; ++i)
+      if (k_lds[i] >= 0) *reinterpret_cast<u32x4*>(ksm + k_lds[i]) = k_one[i] ? u32x4{0x00003F80u, 0u, 0u, 0u} : kreg[i];
+#pragma unroll
+    for (int i = 0; i < NCH_V; ++i) {
+      if (v_lds[i] >= 0) {
+        u32x4 v = vreg[i];
+        if (tail) {
+          const int nvalid = p.nk - (key0 + v_kc[i] * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned keep = ((2 * e < nvalid) ? 0x0000ffffu : 0u) | ((2 * e + 1 < nvalid) ? 0xffff0000u : 0u);
+            v[e] &= keep;
+          }
+        }
+        u32x2* dst = reinterpret_cast<u32x2*>(vsm + v_lds[i]);
+        dst[0] = u32x2{v.x, v.y};
+        dst[2] = u32x2{v.z, v.w};
+      }
+    }
+  };
+
+  f32x16 acc_o[2][NB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_o[qb][nb][i] = 0.f;
+  float mlev[2] = {0.f, 0.f};                            // the reference levels (bf16-exact), -mlev sits in qf[qb][sp].x of the hp lanes
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+
+  const int ntiles = (p.nk + KT - 1) / KT;
+  const int nh = 2 * ntiles;                             // half steps: ht = 2 * tile + half
+
+  auto kfrag = [&](int ht, int s) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(smem + ((ht >> 1) & 3) * BUF + (((ht & 1) * 32 + r) * KSLOTS + 2 * s + h) * 16);
+  };
+  auto vfrag = [&](int ht, int j, int nb) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(smem + ((ht >> 1) & 3) * BUF + K_BYTES + (nb * 32 + r) * VROW + (2 * (ht & 1) + j) * 32 + 16 * h);
+  };
+  auto qk_half = [&](int ht, f32x16 (&S)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 kf = kfrag(ht, s);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+        S[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[qb][s]),
+                                                        s == 0 ? zero16 : S[qb], 0, 0, 0);
+    }
+  };
+  auto mask_tail = [&](int ht, f32x16 (&S)[2]) __attribute__((always_inline)) {
+    const int key0 = ht * 32;
+    if (key0 + 32 > p.nk) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= p.nk) S[qb][i] = -INFINITY;
+        }
+    }
+  };
+  auto pv_half = [&](int ht, const unsigned (&P)[2][8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4 vf = vfrag(ht, j, nb);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const u32x4 pf = {P[qb][4 * j + 0], P[qb][4 * j + 1], P[qb][4 * j + 2], P[qb][4 * j + 3]};
+          acc_o[qb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc_o[qb][nb], 0, 0, 0);
+        }
+      }
+  };
+
+  auto step = [&](auto hpv, auto hnx, auto evn, int ht, f32x16 (&Sc)[2], f32x16 (&Sn)[2], const unsigned (&Pp)[2][8],
+                  unsigned (&Pc)[2][8]) __attribute__((always_inline)) {
+    constexpr bool has_prev = decltype(hpv)::value, has_next = decltype(hnx)::value, even = decltype(evn)::value;
+    if constexpr (even) {
+      // a new tile: tile t+1 is in LDS for everyone and everyone is done with tile t-2 (its V half 1 was read in step (t-1, 0))
+      const int t = ht >> 1;
+      if (t > 0) __syncthreads();
+      if (t + 2 < ntiles) {
+        store_tile((t + 2) * KT, smem + ((t + 2) & 3) * BUF);
+        if (t + 3 < ntiles) load_tile((t + 3) * KT);
+      }
+    }
+    unsigned orv = 0u;
+    auto exp_unit = [&](int u) __attribute__((always_inline)) {
+      const int qb = u >> 3, j = u & 7;
+      const float p0 = __builtin_amdgcn_exp2f(Sc[qb][2 * j]), p1 = __builtin_amdgcn_exp2f(Sc[qb][2 * j + 1]);
+      Pc[qb][j] = pack2(p0, p1);
+      orv |= Pc[qb][j];
+    };
+    if constexpr (has_prev && has_next) {
+      // the steady step: per fragment [LDS read of fragment f + PF | the TWO MFMAs of fragment f | its share of the 16 exponential units]
+      constexpr int NPV = 2 * NB, NF = NPV + KS, NU = 16, PF = 2;
+      auto frag = [&](int f) __attribute__((always_inline)) -> u32x4 { return f < NPV ? vfrag(ht - 1, f / NB, f % NB) : kfrag(ht + 1, f - NPV); };
+      u32x4 fr[PF + 1];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) fr[f] = frag(f);
+      int u = 0;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        if (f + PF < NF) fr[(f + PF) % (PF + 1)] = frag(f + PF);
+        const u32x4 a = fr[f % (PF + 1)];
+        if (f < NPV) {
+          const int j = f / NB, nb = f % NB;
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            const u32x4 pf = {Pp[qb][4 * j + 0], Pp[qb][4 * j + 1], Pp[qb][4 * j + 2], Pp[qb][4 * j + 3]};
+            acc_o[qb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf), acc_o[qb][nb], 0, 0, 0);
+          }
+        } else {
+          const int sx = f - NPV;
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            Sn[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[qb][sx]),
+                                                             sx == 0 ? zero16 : Sn[qb], 0, 0, 0);
+        }
+        const int nu = NU / NF + (f < NU % NF ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < nu; ++k) exp_unit(u++);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if constexpr (has_prev) pv_half(ht - 1, Pp);
+      if constexpr (has_next) qk_half(ht + 1, Sn);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) exp_unit(u);
+    }
+    if constexpr (has_next) mask_tail(ht + 1, Sn);       // (a uniform test: only the last tile can hold keys >= nk)
+    if (__any(ht == 0 || (orv & 0x40004000u) != 0u)) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float mx = Sc[qb][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, Sc[qb][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float want = ht == 0 ? mx + BIAS : fmaxf(mx + BIAS, 0.f);
+        // the new level must be a bf16 number (it travels as an element of Q): round, then move by the EXACT difference
+        const float mnew = __builtin_bit_cast(float, pack2(0.f, mlev[qb] + want) & 0xffff0000u);
+        const float delta = mnew - mlev[qb];
+        mlev[qb] = mnew;
+        if (h == hp) qf[qb][sp].x = pack2(-mnew, 0.f);
+        if (ht != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_o[qb][nb][i] *= alpha;
+        }
+        if (has_next) {                                  // S(ht+1) was taken against the old level
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Sn[qb][i] -= delta;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Pc[qb][j] = pack2(__builtin_amdgcn_exp2f(Sc[qb][2 * j] - delta), __builtin_amdgcn_exp2f(Sc[qb][2 * j + 1] - delta));
+      }
+    }
+  };
+
+  // prologue: tiles 0 and 1 in LDS, tile 2 in the staging registers, S(0)
+  load_tile(0);
+  store_tile(0, smem);
+  if (ntiles > 1) {
+    load_tile(KT);
+    store_tile(KT, smem + BUF);
+  }
+  if (ntiles > 2) load_tile(2 * KT);
+  __syncthreads();
+  f32x16 S0[2], S1[2];
+  unsigned P0[2][8], P1[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P0[qb][j] = P1[qb][j] = 0u;
+  qk_half(0, S0);
+  mask_tail(0, S0);
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  step(F_{}, T_{}, T_{}, 0, S0, S1, P1, P0);             // nh >= 2: the first step always has a successor
+  for (int ht = 1; ht + 1 < nh; ht += 2) {               // steady steps 1 .. nh - 2 (odd, then even: one tile per trip)
+    step(T_{}, T_{}, F_{}, ht, S1, S0, P0, P1);
+    step(T_{}, T_{}, T_{}, ht + 1, S0, S1, P1, P0);
+  }
+  step(T_{}, F_{}, F_{}, nh - 1, S1, S0, P0, P1);        // nh is even: the last step is an odd one
+  pv_half(nh - 1, P1);
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float lsel = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (32 * nb + 8 * g == D) lsel = acc_o[qb][nb][4 * g];
+    const float inv = 1.0f / __shfl(lsel, r, 64);
+    const int qi = q0 + 32 * qb + r;
+    if (qi < p.nq) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * nb + 8 * g + 4 * h;
+          if (d < D) {
+            float v[4] = {acc_o[qb][nb][4 * g + 0] * inv, acc_o[qb][nb][4 * g + 1] * inv, acc_o[qb][nb][4 * g + 2] * inv,
+                          acc_o[qb][nb][4 * g + 3] * inv};
+            Elem<bf16_t>::store4(O + (long long)qi * p.ldo + d, v);
+          }
+        }
+    }
+  }
+}
+
 template <int KS, int NB>
 int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
   SaspaAttnParams p = p0;
@@ -1096,6 +1426,18 @@ int launch_attn(const SaspaAttnParams& p0, hipStream_t s) {
           // -0.5 % at (16, 8, 4096, 4096, 40) and -1.5 % at 5 632 keys on the V^T path with the ones row, but +3.7 % at d = 64 without
           // the ones row and +7.7 % on the row-major-V path (236 against 202 registers) -- the barrier is not what the step waits
           // for.  Taken where it wins; SASPA_ATTN_RING=4: the four-slot ring everywhere (A/B knob, read per launch)
+          // v4 (64 queries per wave, 32-key half steps, the level in the head dimension's padding): d = 40 with V^T;
+          // SASPA_ATTN_V4=0 keeps v3, =2 takes v4 for every eligible launch (A/B / test knob, read per launch)
+          if constexpr (KS == 3 && NB == 2) {
+            const char* v4e = getenv("SASPA_ATTN_V4");
+            const long long wg16 = (long long)((p.nq + 511) / 512) * p.heads * p.batch;
+            const int v4 = v4e ? atoi(v4e) : 1;          // 0: never, 1: from two workgroups per CU on, 2: whenever the shape allows (tests)
+            if (!rm && p.D == 40 && v4 != 0 && (wg16 >= 512 || v4 == 2)) {
+              hipLaunchKernelGGL((flash_attn_v4_kernel<KS, NB, 8>), dim3((p.nq + 511) / 512, p.heads, p.batch), dim3(512), 0, s, p);
+              SASPA_CHECK_LAUNCH();
+              return 0;
+            }
+          }
           const char* re = getenv("SASPA_ATTN_RING");
           if constexpr (KS == 3 && NB == 2) {
             if (!rm && p.D < 32 * NB && !(re && atoi(re) == 4)) {

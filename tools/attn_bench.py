@@ -4,7 +4,8 @@ Columns: v1 = plain queries (scale applied per score); pre0 / pre1 / pre2 = pres
 through the v1 loop / the v2 loop with one LDS buffer / the v2 loop with two buffers and one barrier per tile
 (SASPA_ATTN_MODE = 0 / 1 / 2); pre4 = the software-pipelined v3 loop, 8 waves per workgroup (mode 4); auto = the shipped dispatch rule;
 rm = auto with V ROW-MAJOR (SASPA_ATTN_V_ROWMAJOR: the V columns of a fused Q | K | V buffer, transposed LDS reads); ring4 / rm4 = auto / rm
-with SASPA_ATTN_RING=4 (v3 on its four-slot ring, one barrier per 64-key step, instead of six slots and one barrier per two steps).  usage: python tools/attn_bench.py [quick] [512x704]"""
+with SASPA_ATTN_RING=4 (v3 on its four-slot ring, one barrier per 64-key step, instead of six slots and one barrier per two steps); v3 = auto
+with SASPA_ATTN_V4=0 (d = 40: the v3 loop instead of round 6's 64-queries-per-wave kernel; pre4 / ring4 are v3 too).  usage: python tools/attn_bench.py [quick] [512x704]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import saspa_aug_amd  # noqa: F401
@@ -29,7 +30,7 @@ for (B, H, NQ, NK, D) in shapes:
     vrm = qkv[:, :, 2 * C:]
     vt.copy_(vrm.transpose(1, 2)[:, :, :NK]) if vt.shape[2] == NK else vt[:, :, :NK].copy_(vrm.transpose(1, 2))
     arms = [("v1", q, False, None), ("pre0", qs, True, "0"), ("pre2", qs, True, "2"), ("pre4", qs, True, "4"), ("auto", qs, True, ""),
-            ("ring4", qs, True, "ring4"), ("rm", qs, True, "rm"), ("rm4", qs, True, "rm4")]
+            ("v3", qs, True, "v3"), ("ring4", qs, True, "ring4"), ("rm", qs, True, "rm"), ("rm4", qs, True, "rm4")]
     best = {a[0]: [] for a in arms}
     ref = None
     for rnd in range(ROUNDS + 1):
@@ -39,6 +40,10 @@ for (B, H, NQ, NK, D) in shapes:
                 os.environ["SASPA_ATTN_RING"] = "4"
             else:
                 os.environ.pop("SASPA_ATTN_RING", None)
+            if mode in ("v3", "ring4", "pre4"):               # without the 64-queries-per-wave kernel of round 6 (d = 40 only)
+                os.environ["SASPA_ATTN_V4"] = "0"
+            else:
+                os.environ.pop("SASPA_ATTN_V4", None)
             if mode and mode.isdigit():
                 os.environ["SASPA_ATTN_MODE"] = mode
             else:
@@ -57,6 +62,7 @@ for (B, H, NQ, NK, D) in shapes:
                 print(f"   {name}: max |out - v1| = {err:.3e}", flush=True)
     os.environ.pop("SASPA_ATTN_MODE", None)
     os.environ.pop("SASPA_ATTN_RING", None)
+    os.environ.pop("SASPA_ATTN_V4", None)
     fl = 4.0 * B * H * NQ * NK * D
     line = "  ".join(f"{n} {sorted(v)[len(v) // 2]:8.1f} us {fl / sorted(v)[len(v) // 2] / 1e6:6.1f} TF/s" for n, v in best.items())
     print(f"B={B} H={H} nq={NQ} nk={NK} d={D}: {line}", flush=True)
